@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the Viterbi scan path on MI355X.
+
+One "step" = one pass of the cost kernels (viterbi_null + viterbi_cost, what every
+window pays: c-core/thread.c:114-117) over one batch of synthetic windows that is
+already resident in HBM.  Workload at N=1: BASELINE.json configs[1] -- the three
+minifam profiles (K = 173/241/162) x 1000 synthetic 3 kb reads (iid ACGT, seed
+20250310+i, 10 % with a planted error-bearing domain), one window per pair.  With N
+ranks the reads are sharded over ranks (weak scaling: every rank scores 1000 reads of
+its own against the profiles), no data-path collective; hit records are gathered
+with RCCL after the timed region.
+
+Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json, plus
+  roofline     -- algorithmic bytes (20 B per DP cell) / measured kernel time
+  cpu_baseline -- the reference's own viterbi.c (oracle/_ref, kind "reference") or the
+                  oracle restatement (kind "port") on a bounded sample, host cores stated
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_CELL = 20.0  # five fp32 match-emission operands per DP cell (cost pass)
+SEED = 20250310
+
+
+def synth_reads(nreads, length, consensus, rank=0):
+    """iid-uniform ACGT reads; every 10th carries one planted domain: a profile consensus
+    back-translated with a fixed codon per amino acid, then 10 % substitutions, 3 %
+    insertions, 3 % deletions."""
+    codon = {a: c for a, c in zip("ACDEFGHIKLMNPQRSTVWY",
+                                  ["GCT", "TGT", "GAT", "GAA", "TTT", "GGT", "CAT", "ATT", "AAA", "CTG", "ATG",
+                                   "AAT", "CCT", "CAA", "CGT", "TCT", "ACT", "GTT", "TGG", "TAT"])}
+    lut = {"A": 0, "C": 1, "G": 2, "T": 3}
+    reads = []
+    for i in range(nreads):
+        rng = np.random.default_rng(SEED + rank * nreads + i)
+        r = rng.integers(0, 4, size=length).astype(np.uint8)
+        if i % 10 == 0 and consensus:
+            cons = consensus[i // 10 % len(consensus)]
+            dom = np.array([lut[ch] for a in cons for ch in codon.get(a.upper(), "GCT")], dtype=np.uint8)
+            out = []
+            for b in dom:
+                u = rng.random()
+                if u < 0.03:
+                    continue
+                if u < 0.06:
+                    out.append(rng.integers(0, 4))
+                out.append(rng.integers(0, 4) if rng.random() < 0.10 else b)
+            dom = np.array(out, dtype=np.uint8)[: max(1, length - 10)]
+            at = int(rng.integers(0, length - len(dom) + 1))
+            r[at : at + len(dom)] = dom
+        reads.append(r)
+    return reads
+
+
+def cpu_baseline(db, reads, cores, budget_s=15.0):
+    """The reference's per-window work on the host, on a bounded sample of the same workload."""
+    from dcp_testlib import oracle, reflib
+
+    orc = oracle()
+    ref = reflib()
+    prof = orc.setup_profile(db.proteins[0])
+    kind = "reference" if ref is not None else "port"
+    # ~0.2 GCUPS per AVX2 core: size the sample for about budget_s seconds
+    per_read = prof.K * len(reads[0])
+    n = int(max(cores, min(len(reads), budget_s * 0.15e9 * (cores if ref else 0.02) / per_read)))
+    sample = reads[:n]
+    if ref is not None:
+        xts = np.stack([orc.xtrans(max(len(r) // 3, 1), True, False) for r in sample])
+        off = np.zeros(n + 1, np.int64)
+        np.cumsum([len(r) for r in sample], out=off[1:])
+        secs, _ = ref.bench(prof, xts, np.concatenate(sample), off, cores)
+    else:
+        t0 = time.time()
+        for r in sample:
+            xt = orc.xtrans(max(len(r) // 3, 1), True, False)
+            orc.null(prof, xt, r)
+            orc.cost(prof, xt, r)
+        secs = time.time() - t0
+        cores = 1
+    cells = float(prof.K) * float(sum(len(r) for r in sample))
+    return {"value": cells / secs / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
+            "sample": f"{n} of the {len(reads)} reads x profile 0 (K={prof.K}), viterbi_null+viterbi_cost, "
+                      f"{secs:.1f} s on {cores} host thread(s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=1000)
+    ap.add_argument("--read-len", type=int, default=3000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import deciphon_amd
+    from dcp_testlib import GOLDEN
+    from oracle.dcp_reader import read_dcp
+
+    dcp = os.path.join(GOLDEN, "minifam.dcp")
+    db = read_dcp(dcp)
+    consensus = [p.consensus for p in db.proteins]
+    reads = synth_reads(args.reads, args.read_len, consensus, rank)
+
+    eng = deciphon_amd.Engine(local_rank)
+    eng.load_dcp(dcp)
+    eng.commit()
+    eng.set_sequences(reads)
+    eng.set_mode(True, False)
+    nprof = eng.num_profiles
+    wins = [(p, s, 0, len(reads[s])) for p in range(nprof) for s in range(len(reads))]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    # warm-up launches are untimed inside cost_bench; the HIP-event time covers exactly `steps` launches
+    ms, cells, nul, alt = eng.cost_bench(wins, args.warmup, args.steps)
+    barrier()
+    wall = time.perf_counter() - t0
+    kernel_s = ms * 1e-3 * args.steps
+
+    t = torch.tensor([kernel_s], dtype=torch.float64, device=f"cuda:{local_rank}")
+    c = torch.tensor([cells], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        # the path's only exchange: hit records (lrt >= 0) gathered to every rank over RCCL
+        lrt = -2.0 * ((-nul) - (-alt))
+        hits = torch.tensor([int((lrt >= 0).sum())], dtype=torch.int64, device=f"cuda:{local_rank}")
+        gathered = [torch.zeros_like(hits) for _ in range(world)]
+        dist.all_gather(gathered, hits)
+    t_max = float(t.item())
+    total_cells = float(c.item())
+
+    if rank == 0:
+        gcups = total_cells * args.steps / t_max / 1e9
+        per_gpu_gbps = (cells * BYTES_PER_CELL) / (ms * 1e-3) / 1e9
+        out = {
+            "metric": "GCUPS (Viterbi DP cell updates/sec)", "value": gcups, "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"minifam.dcp (K=173,241,162) x {args.reads} synthetic {args.read_len} nt reads "
+                                   f"per GPU, one window per pair, viterbi_null+viterbi_cost",
+                       "profiles": nprof, "reads_per_gpu": args.reads, "read_len": args.read_len,
+                       "parallelism": f"reads sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": per_gpu_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": per_gpu_gbps / HBM_PEAK_GBPS, "traffic": None,
+                         "note": "algorithmic 20 B/cell; emission rows are re-read from L2, so frac may exceed "
+                                 "the HBM share; see DESIGN.md"},
+            "wall_s_incl_staging": wall,
+        }
+        if not args.no_cpu_baseline:
+            cores = min(os.cpu_count() or 1, 16)
+            out["cpu_baseline"] = cpu_baseline(db, reads, cores)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

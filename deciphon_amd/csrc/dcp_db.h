@@ -1,0 +1,69 @@
+// dcp_db.h -- reader of pressed Deciphon databases (.dcp).
+//
+// Replaces, for the scan path, c-core/database_reader.c:26-80 (header),
+// c-core/protein_reader.c:29-128 (partition offsets from protein_sizes) and
+// c-core/protein.c:283-351 (protein_unpack).  The reference reads through the
+// third-party lio/lite_pack MessagePack library; this is an own reader of the
+// MessagePack subset the writer emits (c-core/database_writer.c:95-193,
+// c-core/protein.c:234-281), accepting both encodings of numeric arrays that
+// exist in the wild: `bin` + native-endian floats (current
+// writer, c-core/write.c:59-66) and the legacy big-endian `ext` types 8 / 6 of
+// the committed fixture control/tests/files/minifam.dcp.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+struct DcpProtein
+{
+  std::string accession;
+  std::string consensus;
+  int gencode = 0;
+  int core_size = 0;
+  std::vector<float> null_emission; // [1364] log-probs
+  std::vector<float> bg_emission;   // [1364]
+  std::vector<float> trans;         // [(K+1)*7]  MM MI MD IM II DM DD
+  std::vector<float> emission;      // [(K+1)*1364] node-major
+  std::vector<float> BMk;           // [K]
+};
+
+struct DcpDbHeader
+{
+  int magic_number = 0;
+  int version = 0;
+  int entry_dist = 0;
+  float epsilon = 0;
+  bool has_ga = false;
+  std::string abc_symbols;
+  int abc_typeid = 0;
+  std::string amino_symbols;
+  std::vector<uint32_t> protein_sizes;
+};
+
+class DcpDbReader
+{
+public:
+  DcpDbReader() = default;
+  ~DcpDbReader();
+  DcpDbReader(DcpDbReader const &) = delete;
+  DcpDbReader &operator=(DcpDbReader const &) = delete;
+
+  // all return 0 or a DCP_E* code
+  int open(char const *path);
+  void close();
+  DcpDbHeader const &header() const { return header_; }
+  int num_proteins() const { return (int)header_.protein_sizes.size(); }
+  // byte offset of protein i inside the file (protein_reader's partition offsets)
+  int64_t protein_offset(int i) const { return offsets_[(size_t)i]; }
+  int read_protein(int i, DcpProtein &out) const;
+
+private:
+  uint8_t const *data_ = nullptr;
+  size_t size_ = 0;
+  int fd_ = -1;
+  DcpDbHeader header_;
+  std::vector<int64_t> offsets_;
+};
+
+// c-core/partition_size.c:13-16
+long dcp_partition_size(long nelems, long nparts, long idx);

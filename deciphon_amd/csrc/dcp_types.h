@@ -1,0 +1,48 @@
+// dcp_types.h -- plain structs shared by host code, HIP kernels and the wave emulator.
+#pragma once
+#include <stdint.h>
+
+#define DCP_TABLE_SIZE 1364  // 4+16+64+256+1024 quasi-codon codes, c-core/viterbi.c:13
+#define DCP_NUM_TRANS 8      // BM MM MI MD IM II DM DD, c-core/viterbi.h:22-32
+#define DCP_NUM_XTRANS 13    // RR SN NN SB NB EB JB EJ JJ EC CC ET CT, c-core/viterbi.h:4-19
+#define DCP_XT_STRIDE 16     // floats per row of the special-transition table
+#define DCP_REF_LANES 8      // SIMD width of the reference build whose E tie rule is reproduced (-mavx2)
+#define DCP_MODEL_MAX 16384  // c-core/model.h:12
+
+enum { DCP_BM, DCP_MM, DCP_MI, DCP_MD, DCP_IM, DCP_II, DCP_DM, DCP_DD };
+enum { DCP_RR, DCP_SN, DCP_NN, DCP_SB, DCP_NB, DCP_EB, DCP_JB, DCP_EJ, DCP_JJ, DCP_EC, DCP_CC, DCP_ET, DCP_CT };
+
+// One sequence position: codes of the 1..5-mers that END at this position,
+// i.e. code_fn(pos - t, t) for t = 1..5 in c[t-1] (0 where the t-mer would start
+// before the sequence).  16 bytes so that a DP row costs one scalar dwordx4 load.
+struct DcpCodeRow
+{
+  uint16_t c[8];
+};
+
+// A profile resident in HBM, in DP-parameter space (costs = -log-prob, +inf =
+// impossible), padded to Kp = 64*Q*W positions with +inf.  All arrays live in
+// one device pool of floats; the fields are offsets into it (in floats), so that
+// kernels address them as kernel-argument base + scalar offset.
+struct DcpProfileDev
+{
+  int32_t K;         // core size
+  int32_t Kp;        // padded row length in floats
+  int32_t Q;         // positions per lane
+  int32_t W;         // waves per problem (1 for K <= 256)
+  int64_t match_off; // [1364][Kp] code-major match emissions
+  int64_t trans_off; // [8][Kp]
+  int64_t null_off;  // [1364]
+  int64_t bg_off;    // [1364]
+};
+
+// One (profile x sequence-window) DP problem.
+struct DcpProblem
+{
+  int32_t profile;  // index into the DcpProfileDev array
+  int32_t L;        // window length
+  int64_t code_row; // index of the window's position 0 in the DcpCodeRow array (row l of the DP reads code_row + l)
+  int32_t xt_row;   // row of the special-transition table = max(L/3, 1), c-core/thread.c:112
+  int32_t out;      // slot in the output arrays
+  int64_t trellis;  // path pass: offset (in bytes) of this problem's trellis in the arena
+};

@@ -1,0 +1,619 @@
+// engine.cpp -- device-resident state and the C ABI of include/deciphon_hip.h.
+//
+// HBM layout (one engine = one GPU):
+//   pool      float[]          all profiles back to back; per profile
+//                              match[1364][Kp] | trans[8][Kp] | null[1364] | bg[1364],
+//                              Kp = 64*Q, padding = +inf (DcpProfileDev holds the offsets)
+//   profiles  DcpProfileDev[]
+//   code_rows DcpCodeRow[]     per sequence len+1 rows of 16 B (built on the GPU
+//                              from 1 B/nt by dcp_encode_kernel)
+//   xt_table  float[S+1][16]   special transitions per amino length S (host-computed:
+//                              they need double-precision log, c-core/xtrans.c:26-45)
+//   problems  DcpProblem[]     sorted by (Q, profile) so that neighbouring
+//                              workgroups hit the same emission table in L2
+//   out       float[]          (null, alt) per window
+//   arena     bytes            trellises of the path pass
+#include "../../include/deciphon_hip.h"
+#include "dcp_db.h"
+#include "dcp_errors.h"
+#include "dcp_types.h"
+#include "host_logic.h"
+#include "viterbi_kernels.h"
+
+#include <algorithm>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace
+{
+
+template <class T> struct DevBuf
+{
+  T *p = nullptr;
+  size_t cap = 0; // elements
+  ~DevBuf() { release(); }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  hipError_t reserve(size_t n)
+  {
+    if (n <= cap) return hipSuccess;
+    release();
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+    if (e != hipSuccess)
+    {
+      p = nullptr;
+      return e;
+    }
+    cap = want;
+    return hipSuccess;
+  }
+};
+
+struct HostProfile
+{
+  int K, Kp, Q, W;
+  int64_t pool_off; // floats
+  std::string accession;
+};
+
+struct PathResult
+{
+  int K = 0, L = 0;
+  float score = 0;
+  size_t arena_off = 0; // bytes into host_arena
+  std::vector<int32_t> state_ids, seqsizes;
+};
+
+} // namespace
+
+struct dcp_hip
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // profiles
+  std::vector<float> pool; // host staging
+  std::vector<HostProfile> profiles;
+  size_t committed = 0; // profiles already in HBM
+  size_t committed_floats = 0;
+  DevBuf<float> d_pool;
+  DevBuf<DcpProfileDev> d_profiles;
+
+  // sequences
+  std::vector<int64_t> seq_off, row_off;
+  DevBuf<unsigned char> d_nt;
+  DevBuf<int64_t> d_seq_off, d_row_off;
+  DevBuf<DcpCodeRow> d_rows;
+
+  // mode
+  bool mode_set = false;
+  bool multi_hits = true, hmmer3_compat = false;
+  DevBuf<float> d_xt;
+  int xt_rows = 0;
+  std::vector<float> xt_override; // [rows][DCP_XT_STRIDE], dcp_hip_set_xtrans_table
+
+  // problems / results
+  DevBuf<DcpProblem> d_problems;
+  DevBuf<float> d_out;
+  DevBuf<unsigned char> d_arena;
+  std::vector<unsigned char> host_arena;
+  std::vector<PathResult> paths;
+};
+
+namespace
+{
+
+int fail(dcp_hip *x, int rc, char const *what, hipError_t e = hipSuccess)
+{
+  char buf[256];
+  if (e != hipSuccess)
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else
+    snprintf(buf, sizeof buf, "%s", what);
+  x->err = buf;
+  return rc;
+}
+
+#define HIP_TRY(x, call, rc)                                                   \
+  do                                                                           \
+  {                                                                            \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) return fail((x), (rc), #call, e_);                   \
+  } while (0)
+
+int choose_q(int K) { return (K + 63) / 64; }
+
+int ensure_xt(dcp_hip *x, int rows_needed)
+{
+  if (!x->mode_set) return fail(x, DCP_EFUNCUSE, "dcp_hip_set_mode has not been called");
+  if (rows_needed <= x->xt_rows) return 0;
+  int rows = std::max(rows_needed, 4096);
+  std::vector<float> tab((size_t)rows * DCP_XT_STRIDE, 0.0f);
+  for (int s = 1; s < rows; ++s) dcp_xtrans(s, x->multi_hits, x->hmmer3_compat, tab.data() + (size_t)s * DCP_XT_STRIDE);
+  if (!x->xt_override.empty())
+    memcpy(tab.data(), x->xt_override.data(), std::min(tab.size(), x->xt_override.size()) * sizeof(float));
+  HIP_TRY(x, x->d_xt.reserve(tab.size()), DCP_ENOMEM);
+  HIP_TRY(x, hipMemcpyAsync(x->d_xt.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  x->xt_rows = rows;
+  return 0;
+}
+
+struct Staged
+{
+  std::vector<DcpProblem> problems; // sorted by (Q, profile)
+  int q_begin[DCP_MAX_Q + 2] = {0}; // problems of class Q are [q_begin[Q], q_begin[Q+1])
+  double cells = 0;
+  size_t arena_bytes = 0;
+};
+
+// validates windows and builds the device problem list
+int stage(dcp_hip *x, int n, dcp_hip_window const *w, bool with_trellis, Staged &st)
+{
+  if (n < 0 || (n > 0 && !w)) return fail(x, DCP_EFUNCUSE, "bad window array");
+  if (x->committed != x->profiles.size()) return fail(x, DCP_EFUNCUSE, "profiles not committed");
+  int const nseq = (int)x->seq_off.size() - 1;
+  int max_s = 1;
+  st.problems.resize((size_t)n);
+  size_t arena = 0;
+  for (int i = 0; i < n; ++i)
+  {
+    if (w[i].profile < 0 || w[i].profile >= (int)x->profiles.size()) return fail(x, DCP_EFUNCUSE, "bad profile index");
+    if (w[i].seq < 0 || w[i].seq >= nseq) return fail(x, DCP_EFUNCUSE, "bad sequence index");
+    int64_t const len = x->seq_off[(size_t)w[i].seq + 1] - x->seq_off[(size_t)w[i].seq];
+    if (w[i].start < 0 || w[i].stop < w[i].start || w[i].stop > len) return fail(x, DCP_EFUNCUSE, "bad window range");
+    int const L = w[i].stop - w[i].start;
+    if (L < 1) return fail(x, DCP_EZEROSEQ, "empty window");
+    HostProfile const &hp = x->profiles[(size_t)w[i].profile];
+    DcpProblem &p = st.problems[(size_t)i];
+    p.profile = w[i].profile;
+    p.L = L;
+    p.code_row = x->row_off[(size_t)w[i].seq] + w[i].start;
+    p.xt_row = std::max(L / 3, 1); // c-core/thread.c:112
+    p.out = i;
+    p.trellis = 0;
+    max_s = std::max(max_s, p.xt_row);
+    st.cells += (double)hp.K * (double)L;
+    if (with_trellis)
+    {
+      p.trellis = (int64_t)arena;
+      size_t bytes = ((size_t)L + 1) * 4 + ((size_t)L + 1) * (size_t)hp.K * 2;
+      arena += (bytes + 15) & ~(size_t)15;
+    }
+  }
+  st.arena_bytes = arena;
+  std::stable_sort(st.problems.begin(), st.problems.end(), [&](DcpProblem const &a, DcpProblem const &b) {
+    int qa = x->profiles[(size_t)a.profile].Q, qb = x->profiles[(size_t)b.profile].Q;
+    if (qa != qb) return qa < qb;
+    return a.profile < b.profile;
+  });
+  int i = 0;
+  for (int q = 1; q <= DCP_MAX_Q; ++q)
+  {
+    st.q_begin[q] = i;
+    while (i < n && x->profiles[(size_t)st.problems[(size_t)i].profile].Q == q) ++i;
+  }
+  st.q_begin[DCP_MAX_Q + 1] = i;
+  if (i != n) return fail(x, DCP_ELARGECORESIZE, "profile longer than the single-wave kernels cover");
+  int rc = ensure_xt(x, max_s + 1);
+  if (rc) return rc;
+  HIP_TRY(x, x->d_problems.reserve((size_t)std::max(n, 1)), DCP_ENOMEM);
+  if (n)
+    HIP_TRY(x, hipMemcpyAsync(x->d_problems.p, st.problems.data(), (size_t)n * sizeof(DcpProblem),
+                              hipMemcpyHostToDevice, x->stream),
+            DCP_EFUNCUSE);
+  return 0;
+}
+
+DcpLaunch launch_args(dcp_hip *x, Staged const &st, int q)
+{
+  DcpLaunch a;
+  a.pool = x->d_pool.p;
+  a.profiles = x->d_profiles.p;
+  a.problems = x->d_problems.p + st.q_begin[q];
+  a.code_rows = x->d_rows.p;
+  a.xt_table = x->d_xt.p;
+  a.out = x->d_out.p;
+  a.arena = x->d_arena.p;
+  a.nprob = st.q_begin[q + 1] - st.q_begin[q];
+  a.stream = x->stream;
+  return a;
+}
+
+int launch_cost_all(dcp_hip *x, Staged const &st)
+{
+  for (int q = 1; q <= DCP_MAX_Q; ++q)
+  {
+    DcpLaunch a = launch_args(x, st, q);
+    HIP_TRY(x, dcp_launch_cost(q, a), DCP_EFUNCUSE);
+  }
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int dcp_hip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+struct dcp_hip *dcp_hip_new(int device)
+{
+  int n = dcp_hip_device_count();
+  if (device < 0 || device >= n) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  dcp_hip *x = new dcp_hip;
+  x->device = device;
+  if (hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) != hipSuccess)
+  {
+    delete x;
+    return nullptr;
+  }
+  x->seq_off.assign(1, 0);
+  x->row_off.assign(1, 0);
+  return x;
+}
+
+void dcp_hip_del(struct dcp_hip *x)
+{
+  if (!x) return;
+  (void)hipSetDevice(x->device);
+  if (x->stream)
+  {
+    (void)hipStreamSynchronize(x->stream);
+    (void)hipStreamDestroy(x->stream);
+  }
+  delete x;
+}
+
+char const *dcp_hip_strerror(struct dcp_hip const *x) { return x ? x->err.c_str() : "no engine"; }
+
+static int add_slot(dcp_hip *x, int K, char const *accession, float **trans, float **match, float **nul, float **bg,
+                    int *index)
+{
+  if (K < 1 || K > DCP_MODEL_MAX) return fail(x, DCP_ELARGECORESIZE, "core size out of range");
+  int const Q = choose_q(K);
+  if (Q > DCP_MAX_Q) return fail(x, DCP_ELARGECORESIZE, "core size beyond 64*DCP_MAX_Q not supported yet");
+  HostProfile hp;
+  hp.K = K;
+  hp.Q = Q;
+  hp.W = 1;
+  hp.Kp = 64 * Q;
+  hp.pool_off = (int64_t)x->pool.size();
+  hp.accession = accession ? accession : "";
+  size_t const floats = (size_t)(DCP_TABLE_SIZE + DCP_NUM_TRANS) * hp.Kp + 2 * DCP_TABLE_SIZE;
+  // keep every profile 16-byte aligned for the dwordx4 row loads
+  size_t const padded = (floats + 3) & ~(size_t)3;
+  x->pool.resize(x->pool.size() + padded, INFINITY);
+  float *base = x->pool.data() + hp.pool_off;
+  *match = base;
+  *trans = base + (size_t)DCP_TABLE_SIZE * hp.Kp;
+  *nul = *trans + (size_t)DCP_NUM_TRANS * hp.Kp;
+  *bg = *nul + DCP_TABLE_SIZE;
+  if (index) *index = (int)x->profiles.size();
+  x->profiles.push_back(hp);
+  return 0;
+}
+
+int dcp_hip_add_profile(struct dcp_hip *x, int K, float const *trans, float const *match, float const *null_cost,
+                        float const *bg_cost, int *index)
+{
+  if (!x || !trans || !match || !null_cost || !bg_cost) return DCP_EFUNCUSE;
+  float *t, *m, *n, *b;
+  int rc = add_slot(x, K, nullptr, &t, &m, &n, &b, index);
+  if (rc) return rc;
+  int const Kp = x->profiles.back().Kp;
+  for (int id = 0; id < DCP_NUM_TRANS; ++id) memcpy(t + (size_t)id * Kp, trans + (size_t)id * K, sizeof(float) * K);
+  for (int c = 0; c < DCP_TABLE_SIZE; ++c) memcpy(m + (size_t)c * Kp, match + (size_t)c * K, sizeof(float) * K);
+  memcpy(n, null_cost, sizeof(float) * DCP_TABLE_SIZE);
+  memcpy(b, bg_cost, sizeof(float) * DCP_TABLE_SIZE);
+  return 0;
+}
+
+int dcp_hip_add_protein(struct dcp_hip *x, int K, float const *node_trans, float const *node_emission,
+                        float const *BMk, float const *null_lprob, float const *bg_lprob, int *index)
+{
+  if (!x || !node_trans || !node_emission || !BMk || !null_lprob || !bg_lprob) return DCP_EFUNCUSE;
+  float *t, *m, *n, *b;
+  int rc = add_slot(x, K, nullptr, &t, &m, &n, &b, index);
+  if (rc) return rc;
+  dcp_setup_profile(K, x->profiles.back().Kp, node_trans, node_emission, BMk, null_lprob, bg_lprob, t, m, n, b);
+  return 0;
+}
+
+int dcp_hip_load_dcp(struct dcp_hip *x, char const *path, int first, int count)
+{
+  if (!x || !path) return DCP_EFUNCUSE;
+  DcpDbReader db;
+  int rc = db.open(path);
+  if (rc) return fail(x, rc, "cannot open database");
+  int const N = db.num_proteins();
+  if (first < 0 || first > N) return fail(x, DCP_EINVALPART, "first protein out of range");
+  int const last = count < 0 ? N : std::min(N, first + count);
+  DcpProtein p;
+  for (int i = first; i < last; ++i)
+  {
+    if ((rc = db.read_protein(i, p))) return fail(x, rc, "cannot read protein");
+    float *t, *m, *n, *b;
+    if ((rc = add_slot(x, p.core_size, p.accession.c_str(), &t, &m, &n, &b, nullptr))) return rc;
+    dcp_setup_profile(p.core_size, x->profiles.back().Kp, p.trans.data(), p.emission.data(), p.BMk.data(),
+                      p.null_emission.data(), p.bg_emission.data(), t, m, n, b);
+  }
+  return 0;
+}
+
+int dcp_hip_num_profiles(struct dcp_hip const *x) { return x ? (int)x->profiles.size() : 0; }
+
+int dcp_hip_profile_core_size(struct dcp_hip const *x, int i)
+{
+  if (!x || i < 0 || i >= (int)x->profiles.size()) return -1;
+  return x->profiles[(size_t)i].K;
+}
+
+char const *dcp_hip_profile_accession(struct dcp_hip const *x, int i)
+{
+  if (!x || i < 0 || i >= (int)x->profiles.size()) return nullptr;
+  return x->profiles[(size_t)i].accession.c_str();
+}
+
+int dcp_hip_commit_profiles(struct dcp_hip *x)
+{
+  if (!x) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  if (x->committed == x->profiles.size()) return 0;
+  // simple policy: (re)upload the whole pool; profiles are added in bulk before a scan
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  HIP_TRY(x, x->d_pool.reserve(x->pool.size()), DCP_ENOMEM);
+  HIP_TRY(x, hipMemcpyAsync(x->d_pool.p, x->pool.data(), x->pool.size() * sizeof(float), hipMemcpyHostToDevice,
+                            x->stream),
+          DCP_EFUNCUSE);
+  std::vector<DcpProfileDev> dev(x->profiles.size());
+  for (size_t i = 0; i < dev.size(); ++i)
+  {
+    HostProfile const &hp = x->profiles[i];
+    dev[i].K = hp.K;
+    dev[i].Kp = hp.Kp;
+    dev[i].Q = hp.Q;
+    dev[i].W = hp.W;
+    dev[i].match_off = hp.pool_off;
+    dev[i].trans_off = dev[i].match_off + (int64_t)DCP_TABLE_SIZE * hp.Kp;
+    dev[i].null_off = dev[i].trans_off + (int64_t)DCP_NUM_TRANS * hp.Kp;
+    dev[i].bg_off = dev[i].null_off + DCP_TABLE_SIZE;
+  }
+  HIP_TRY(x, x->d_profiles.reserve(dev.size()), DCP_ENOMEM);
+  HIP_TRY(x, hipMemcpyAsync(x->d_profiles.p, dev.data(), dev.size() * sizeof(DcpProfileDev), hipMemcpyHostToDevice,
+                            x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  x->committed = x->profiles.size();
+  x->committed_floats = x->pool.size();
+  return 0;
+}
+
+void dcp_hip_clear_profiles(struct dcp_hip *x)
+{
+  if (!x) return;
+  x->pool.clear();
+  x->profiles.clear();
+  x->committed = 0;
+  x->committed_floats = 0;
+}
+
+int dcp_hip_encode(char const *data, int64_t n, uint8_t *out)
+{
+  if (n < 0 || (n > 0 && (!data || !out))) return DCP_EFUNCUSE;
+  return dcp_encode_sequence(data, n, out);
+}
+
+int dcp_hip_set_sequences(struct dcp_hip *x, int nseq, uint8_t const *nt, int64_t const *offsets)
+{
+  if (!x || nseq < 0 || !offsets || (nseq > 0 && !nt)) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  x->seq_off.assign(offsets, offsets + nseq + 1);
+  x->row_off.resize((size_t)nseq + 1);
+  int64_t max_len = 0, rows = 0;
+  if (x->seq_off[0] != 0) return fail(x, DCP_EFUNCUSE, "offsets[0] must be 0");
+  for (int i = 0; i < nseq; ++i)
+  {
+    int64_t len = x->seq_off[(size_t)i + 1] - x->seq_off[(size_t)i];
+    if (len < 0) return fail(x, DCP_EFUNCUSE, "offsets must not decrease");
+    max_len = std::max(max_len, len);
+    x->row_off[(size_t)i] = rows;
+    rows += len + 1;
+  }
+  x->row_off[(size_t)nseq] = rows;
+  int64_t const total = x->seq_off[(size_t)nseq];
+  for (int64_t i = 0; i < total; ++i)
+    if (nt[i] > 3) return fail(x, DCP_ESEQABC, "nucleotide index above 3");
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  HIP_TRY(x, x->d_nt.reserve((size_t)std::max<int64_t>(total, 1)), DCP_ENOMEM);
+  HIP_TRY(x, x->d_seq_off.reserve((size_t)nseq + 1), DCP_ENOMEM);
+  HIP_TRY(x, x->d_row_off.reserve((size_t)nseq + 1), DCP_ENOMEM);
+  HIP_TRY(x, x->d_rows.reserve((size_t)std::max<int64_t>(rows, 1)), DCP_ENOMEM);
+  if (total)
+    HIP_TRY(x, hipMemcpyAsync(x->d_nt.p, nt, (size_t)total, hipMemcpyHostToDevice, x->stream), DCP_EFUNCUSE);
+  HIP_TRY(x, hipMemcpyAsync(x->d_seq_off.p, x->seq_off.data(), ((size_t)nseq + 1) * sizeof(int64_t),
+                            hipMemcpyHostToDevice, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipMemcpyAsync(x->d_row_off.p, x->row_off.data(), ((size_t)nseq + 1) * sizeof(int64_t),
+                            hipMemcpyHostToDevice, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, dcp_launch_encode(x->d_nt.p, x->d_seq_off.p, x->d_row_off.p, nseq, max_len, x->d_rows.p, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  return 0;
+}
+
+int dcp_hip_set_mode(struct dcp_hip *x, int multi_hits, int hmmer3_compat)
+{
+  if (!x) return DCP_EFUNCUSE;
+  bool mh = multi_hits != 0, h3 = hmmer3_compat != 0;
+  if (x->mode_set && (mh != x->multi_hits || h3 != x->hmmer3_compat)) x->xt_rows = 0;
+  x->multi_hits = mh;
+  x->hmmer3_compat = h3;
+  x->mode_set = true;
+  return 0;
+}
+
+int dcp_hip_set_xtrans_table(struct dcp_hip *x, int rows, float const *xt)
+{
+  if (!x || rows < 0 || (rows > 0 && !xt)) return DCP_EFUNCUSE;
+  x->xt_override.assign((size_t)rows * DCP_XT_STRIDE, 0.0f);
+  for (int r = 0; r < rows; ++r)
+    memcpy(x->xt_override.data() + (size_t)r * DCP_XT_STRIDE, xt + (size_t)r * DCP_NUM_XTRANS,
+           sizeof(float) * DCP_NUM_XTRANS);
+  x->xt_rows = 0; // rebuild the device table at the next launch
+  return 0;
+}
+
+void dcp_hip_xtrans(int seq_size, int multi_hits, int hmmer3_compat, float xt[DCP_HIP_NUM_XTRANS])
+{
+  dcp_xtrans(seq_size, multi_hits != 0, hmmer3_compat != 0, xt);
+}
+
+int dcp_hip_cost(struct dcp_hip *x, int n, struct dcp_hip_window const *w, float *null_cost, float *alt_cost)
+{
+  if (!x || (n > 0 && (!null_cost || !alt_cost))) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  Staged st;
+  int rc = stage(x, n, w, false, st);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  if ((rc = launch_cost_all(x, st))) return rc;
+  std::vector<float> out(2 * (size_t)n);
+  HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  for (int i = 0; i < n; ++i)
+  {
+    null_cost[i] = out[2 * (size_t)i];
+    alt_cost[i] = out[2 * (size_t)i + 1];
+  }
+  return 0;
+}
+
+int dcp_hip_cost_bench(struct dcp_hip *x, int n, struct dcp_hip_window const *w, int warmup, int reps, float *ms,
+                       double *cells, float *null_cost, float *alt_cost)
+{
+  if (!x || n <= 0 || reps <= 0 || !ms || !cells) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  Staged st;
+  int rc = stage(x, n, w, false, st);
+  if (rc) return rc;
+  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  for (int i = 0; i < warmup; ++i)
+    if ((rc = launch_cost_all(x, st))) return rc;
+  hipEvent_t e0, e1;
+  HIP_TRY(x, hipEventCreate(&e0), DCP_EFUNCUSE);
+  HIP_TRY(x, hipEventCreate(&e1), DCP_EFUNCUSE);
+  HIP_TRY(x, hipEventRecord(e0, x->stream), DCP_EFUNCUSE);
+  for (int i = 0; i < reps; ++i)
+    if ((rc = launch_cost_all(x, st))) return rc;
+  HIP_TRY(x, hipEventRecord(e1, x->stream), DCP_EFUNCUSE);
+  HIP_TRY(x, hipEventSynchronize(e1), DCP_EFUNCUSE);
+  float total = 0;
+  HIP_TRY(x, hipEventElapsedTime(&total, e0, e1), DCP_EFUNCUSE);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms = total / (float)reps;
+  *cells = st.cells;
+  if (null_cost && alt_cost)
+  {
+    std::vector<float> out(2 * (size_t)n);
+    HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+            DCP_EFUNCUSE);
+    HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+    for (int i = 0; i < n; ++i)
+    {
+      null_cost[i] = out[2 * (size_t)i];
+      alt_cost[i] = out[2 * (size_t)i + 1];
+    }
+  }
+  return 0;
+}
+
+int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
+{
+  if (!x) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  x->paths.clear();
+  Staged st;
+  int rc = stage(x, n, w, true, st);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  HIP_TRY(x, x->d_out.reserve((size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, x->d_arena.reserve(st.arena_bytes), DCP_ENOMEM);
+  for (int q = 1; q <= DCP_MAX_Q; ++q)
+  {
+    DcpLaunch a = launch_args(x, st, q);
+    HIP_TRY(x, dcp_launch_path(q, a), DCP_EFUNCUSE);
+  }
+  x->host_arena.resize(st.arena_bytes);
+  std::vector<float> out((size_t)n);
+  HIP_TRY(x, hipMemcpyAsync(x->host_arena.data(), x->d_arena.p, st.arena_bytes, hipMemcpyDeviceToHost, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  x->paths.resize((size_t)n);
+  for (DcpProblem const &p : st.problems)
+  {
+    PathResult &r = x->paths[(size_t)p.out];
+    r.K = x->profiles[(size_t)p.profile].K;
+    r.L = p.L;
+    r.score = out[(size_t)p.out];
+    r.arena_off = (size_t)p.trellis;
+    uint32_t const *xn = reinterpret_cast<uint32_t const *>(x->host_arena.data() + r.arena_off);
+    uint16_t const *nd = reinterpret_cast<uint16_t const *>(xn + (r.L + 1));
+    if ((rc = dcp_unzip(r.K, r.L, xn, nd, r.state_ids, r.seqsizes))) return fail(x, rc, "trellis_unzip failed");
+  }
+  return 0;
+}
+
+int dcp_hip_path_nsteps(struct dcp_hip const *x, int i)
+{
+  if (!x || i < 0 || i >= (int)x->paths.size()) return -1;
+  return (int)x->paths[(size_t)i].state_ids.size();
+}
+
+int dcp_hip_path_steps(struct dcp_hip const *x, int i, int32_t *state_ids, int32_t *seqsizes)
+{
+  if (!x || i < 0 || i >= (int)x->paths.size() || !state_ids || !seqsizes) return DCP_EFUNCUSE;
+  PathResult const &r = x->paths[(size_t)i];
+  memcpy(state_ids, r.state_ids.data(), r.state_ids.size() * sizeof(int32_t));
+  memcpy(seqsizes, r.seqsizes.data(), r.seqsizes.size() * sizeof(int32_t));
+  return 0;
+}
+
+int dcp_hip_path_trellis(struct dcp_hip const *x, int i, uint32_t const **xnodes, uint16_t const **nodes)
+{
+  if (!x || i < 0 || i >= (int)x->paths.size() || !xnodes || !nodes) return DCP_EFUNCUSE;
+  PathResult const &r = x->paths[(size_t)i];
+  uint32_t const *xn = reinterpret_cast<uint32_t const *>(x->host_arena.data() + r.arena_off);
+  *xnodes = xn;
+  *nodes = reinterpret_cast<uint16_t const *>(xn + (r.L + 1));
+  return 0;
+}
+
+float dcp_hip_path_score(struct dcp_hip const *x, int i)
+{
+  if (!x || i < 0 || i >= (int)x->paths.size()) return NAN;
+  return x->paths[(size_t)i].score;
+}
+
+} // extern "C"

@@ -1,0 +1,324 @@
+// host_logic.cpp -- see host_logic.h
+#include "host_logic.h"
+#include "dcp_errors.h"
+
+#include <initializer_list>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <utility>
+
+void dcp_xtrans(int seq_size, bool multi_hits, bool hmmer3_compat, float xt[DCP_NUM_XTRANS])
+{
+  // The reference evaluates these with double log() on float operands and stores
+  // floats (c-core/xtrans.c:26-45); the same expression shapes are kept so the
+  // roundings agree.
+  float const L = (float)seq_size;
+  float q = 0.0f;
+  float log_q = -INFINITY;
+  if (multi_hits)
+  {
+    q = 0.5f;
+    log_q = (float)log(0.5);
+  }
+  float const denom = L + 2 + q / (1 - q);
+  float const lp = (float)(log(L) - log(denom));
+  float const l1p = (float)(log(2 + q / (1 - q)) - log(denom));
+  float const lr = (float)(log(L) - log(L + 1));
+
+  float NN = lp, CC = lp, JJ = lp;
+  float const NB = l1p, CT = l1p, JB = l1p, RR = lr;
+  float const EJ = log_q;
+  float const EC = (float)log(1 - q);
+  if (hmmer3_compat) NN = CC = JJ = logf(1);
+
+  // c-core/xtrans.c:53-68
+  xt[DCP_RR] = -RR;
+  xt[DCP_SN] = -0 - NN;
+  xt[DCP_NN] = -NN;
+  xt[DCP_SB] = -0 - NB;
+  xt[DCP_NB] = -NB;
+  xt[DCP_EB] = -EJ - JB;
+  xt[DCP_JB] = -JB;
+  xt[DCP_EJ] = -EJ - JJ;
+  xt[DCP_JJ] = -JJ;
+  xt[DCP_EC] = -EC - CC;
+  xt[DCP_CC] = -CC;
+  xt[DCP_ET] = -EC - CT;
+  xt[DCP_CT] = -CT;
+}
+
+void dcp_setup_profile(int K, int Kp, float const *node_trans, float const *node_emission, float const *BMk,
+                       float const *null_lprob, float const *bg_lprob, float *trans, float *match, float *null_cost,
+                       float *bg_cost)
+{
+  for (size_t i = 0; i < (size_t)DCP_NUM_TRANS * Kp; ++i) trans[i] = INFINITY; // viterbi_setup fills +inf
+  for (int k = 0; k < K; ++k) trans[DCP_BM * Kp + k] = -BMk[k];
+  for (int k = 0; k + 1 < K; ++k)
+  {
+    float const *t = node_trans + 7 * (size_t)k; // MM MI MD IM II DM DD, c-core/trans.h:8-27
+    trans[DCP_MM * Kp + k + 1] = -t[0];
+    trans[DCP_MI * Kp + k] = -t[1];
+    trans[DCP_MD * Kp + k + 1] = -t[2];
+    trans[DCP_IM * Kp + k + 1] = -t[3];
+    trans[DCP_II * Kp + k] = -t[4];
+    trans[DCP_DM * Kp + k + 1] = -t[5];
+    trans[DCP_DD * Kp + k + 1] = -t[6];
+  }
+  trans[DCP_MI * Kp + K - 1] = INFINITY;
+  trans[DCP_II * Kp + K - 1] = INFINITY;
+  // node-major [k][code] on disk -> code-major [code][k] rows for the kernels
+  for (int c = 0; c < DCP_TABLE_SIZE; ++c)
+  {
+    null_cost[c] = -null_lprob[c];
+    bg_cost[c] = -bg_lprob[c];
+    float *row = match + (size_t)c * Kp;
+    for (int k = 0; k < K; ++k) row[k] = -node_emission[(size_t)k * DCP_TABLE_SIZE + c];
+    for (int k = K; k < Kp; ++k) row[k] = INFINITY;
+  }
+}
+
+int dcp_encode_sequence(char const *data, int64_t n, uint8_t *out)
+{
+  enum { A, C, G, T, U, NSYM };
+  int64_t count[NSYM] = {0};
+  for (int64_t i = 0; i < n; ++i)
+  {
+    switch (data[i] & ~0x20) // ASCII letters: clear the lowercase bit
+    {
+    case 'A': count[A]++; break;
+    case 'C': count[C]++; break;
+    case 'G': count[G]++; break;
+    case 'T': count[T]++; break;
+    case 'U': count[U]++; break;
+    default: break;
+    }
+  }
+  if (count[T] > 0 && count[U] > 0) return DCP_ENUCLTSEQTU;
+
+  // IUPAC ambiguity codes resolve to the most frequent member base of THIS
+  // sequence, the first listed winning ties (c-core/disambiguate.c:23-35,55-83)
+  auto pick = [&](std::initializer_list<int> set) {
+    int best = *set.begin();
+    for (int s : set)
+      if (count[s] > count[best]) best = s;
+    return best;
+  };
+  int rc = 0;
+  for (int64_t i = 0; i < n; ++i)
+  {
+    char const ch = data[i];
+    bool const letter = (ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z');
+    int sym = -1;
+    switch (letter ? (ch & ~0x20) : 0)
+    {
+    case 'A': sym = A; break;
+    case 'C': sym = C; break;
+    case 'G': sym = G; break;
+    case 'T': sym = T; break;
+    case 'U': sym = U; break;
+    case 'R': sym = pick({A, G}); break;
+    case 'Y': sym = pick({C, T}); break;
+    case 'M': sym = pick({A, C}); break;
+    case 'K': sym = pick({G, T}); break;
+    case 'S': sym = pick({C, G}); break;
+    case 'W': sym = pick({A, T}); break;
+    case 'H': sym = pick({A, C, T}); break;
+    case 'B': sym = pick({C, G, T}); break;
+    case 'V': sym = pick({A, C, G}); break;
+    case 'D': sym = pick({A, G, T}); break;
+    case 'N': sym = pick({A, C, G, T}); break;
+    case 'X': sym = pick({A, C, G, T}); break;
+    default: break;
+    }
+    if (sym < 0)
+    {
+      rc = DCP_ESEQABC;
+      out[i] = 0;
+    }
+    else
+      out[i] = (uint8_t)(sym == U ? 3 : sym);
+  }
+  return rc;
+}
+
+namespace
+{
+enum
+{
+  ST_M = 0 << 14, ST_I = 1 << 14, ST_D = 2 << 14, ST_X = 3 << 14, // c-core/state.h:9-25
+  ST_S = ST_X | 3, ST_N = ST_X | 4, ST_B = ST_X | 5, ST_E = ST_X | 6, ST_J = ST_X | 7, ST_C = ST_X | 8, ST_T = ST_X | 9,
+};
+inline int msb(int id) { return id & (3 << 14); }
+inline bool is_core(int id) { return msb(id) != ST_X; }
+inline int core_idx(int id) { return (id & 0x3FFF) - 1; }
+} // namespace
+
+int dcp_unzip(int K, int L, uint32_t const *xnodes, uint16_t const *nodes, std::vector<int32_t> &state_ids,
+              std::vector<int32_t> &seqsizes)
+{
+  size_t const first = state_ids.size();
+  int state = ST_T; // state_make_end()
+  int stage = L;
+  // a valid trellis walks at most (L+1)*(K+4) steps; anything longer is corrupt
+  int64_t const limit = ((int64_t)L + 1) * ((int64_t)K + 4) + 8;
+  int64_t steps = 0;
+  while (state != ST_S || stage)
+  {
+    if (++steps > limit) return DCP_EINVALSTATE;
+    int size = 0, prev = 0;
+    if (!is_core(state))
+    {
+      uint32_t const x = xnodes[stage];
+      // field offsets/widths: c-core/trellis.h:42-56, c-core/state.h:27-39
+      switch (state)
+      {
+      case ST_N: { unsigned v = x & 0xF; size = (int)(v % 5) + 1; prev = v / 5 ? ST_N : ST_S; break; }
+      case ST_B: { unsigned v = (x >> 4) & 0x3; static int const from[4] = {ST_S, ST_N, ST_E, ST_J}; prev = from[v]; break; }
+      case ST_E: { unsigned v = (x >> 6) & 0x7FFF; prev = (v & 1 ? ST_D : ST_M) | (int)(v / 2 + 1); break; }
+      case ST_C: { unsigned v = (x >> 21) & 0xF; size = (int)(v % 5) + 1; prev = v / 5 ? ST_C : ST_E; break; }
+      case ST_T: { unsigned v = (x >> 25) & 0x1; prev = v ? ST_C : ST_E; break; }
+      case ST_J: { unsigned v = (x >> 26) & 0xF; size = (int)(v % 5) + 1; prev = v / 5 ? ST_J : ST_E; break; }
+      default: return DCP_EINVALSTATE;
+      }
+    }
+    else
+    {
+      int const idx = core_idx(state);
+      if (idx < 0 || idx >= K) return DCP_EINVALSTATE;
+      uint16_t const w = nodes[(size_t)stage * (size_t)K + (size_t)idx];
+      if (msb(state) == ST_M)
+      {
+        unsigned v = w & 0x1F;
+        size = (int)(v % 5) + 1;
+        unsigned s = v / 5;
+        if (s == 0) prev = ST_B;
+        else
+        {
+          if (idx <= 0) return DCP_EINVALSTATE; // BUG_ON(idx <= 0), c-core/trellis.c:72
+          prev = (s == 1 ? ST_M : s == 2 ? ST_I : ST_D) | idx;
+        }
+      }
+      else if (msb(state) == ST_D)
+      {
+        unsigned v = (w >> 5) & 0x1;
+        if (idx <= 0) return DCP_EINVALSTATE;
+        prev = (v ? ST_D : ST_M) | idx;
+      }
+      else
+      {
+        unsigned v = (w >> 6) & 0xF;
+        size = (int)(v % 5) + 1;
+        prev = (v / 5 ? ST_I : ST_M) | (idx + 1);
+      }
+    }
+    state_ids.push_back(state);
+    seqsizes.push_back(size);
+    state = prev;
+    stage -= size;
+    if (stage < 0) return DCP_EINVALSTATE;
+  }
+  state_ids.push_back(state);
+  seqsizes.push_back(0);
+  for (size_t i = first, j = state_ids.size() - 1; i < j; ++i, --j) // imm_path_reverse
+  {
+    std::swap(state_ids[i], state_ids[j]);
+    std::swap(seqsizes[i], seqsizes[j]);
+  }
+  return 0;
+}
+
+void dcp_state_name(int id, char name[8])
+{
+  if (msb(id) == ST_X)
+  {
+    static char const letters[] = "FRGSNBEJCT";
+    int const n = id & 0x3FFF;
+    name[0] = n < 10 ? letters[n] : '?';
+    name[1] = 0;
+    return;
+  }
+  name[0] = msb(id) == ST_M ? 'M' : msb(id) == ST_I ? 'I' : 'D';
+  snprintf(name + 1, 7, "%d", core_idx(id) + 1);
+}
+
+bool dcp_state_is_mute(int id)
+{
+  if (msb(id) == ST_X) return id == ST_S || id == ST_B || id == ST_E || id == ST_T;
+  return msb(id) == ST_D;
+}
+
+bool dcp_find_hit(std::vector<int32_t> const &ids, std::vector<int32_t> const &sizes, DcpHit &hit)
+{
+  int const n = (int)ids.size();
+  int it = 0, pos = 0;
+  while (it < n && ids[it] != ST_B) pos += sizes[it++];
+  if (it >= n) return false;
+  hit.hit_start = pos;
+  hit.begin_step = it;
+  int end = it + 1;
+  int stop = pos;
+  for (;;)
+  {
+    it = end;
+    hit.hit_stop = stop;
+    while (it < n && ids[it] != ST_E) stop += sizes[it++];
+    if (it >= n) break;
+    end = it + 1;
+  }
+  hit.end_step = end;
+  hit.last_hit_pos = hit.hit_stop - 1;
+  return true;
+}
+
+bool DcpWindow::next()
+{
+  if (stop == seq_size) return false;
+  int const stop_miss = stop + 1;
+  int start_miss = start + 1;
+  if (start + last_hit_pos + 1 > start_miss) start_miss = start + last_hit_pos + 1;
+  if (stop_miss - core_size * 4 > start_miss) start_miss = stop_miss - core_size * 4;
+  start = start_miss;
+  int const span = core_size * 50 < 100000 ? core_size * 50 : 100000;
+  stop = start_miss + span;
+  if (stop > seq_size) stop = seq_size;
+  idx += 1;
+  return true;
+}
+
+// c-core/error.c:10-101
+char const *dcp_error_string(int code)
+{
+  static char const *const msg[] = {
+      nullptr,
+      "different alphabets", "failed to close file", "invalid file data", "failed to re-open file",
+      "failed to read from file", "failed to seek file", "failed to get file position", "invalid function usage",
+      "failed to write to file", "failed to get file path", "zero-length sequence", "zero-length model",
+      "no partition", "failed to decode into codon", "model is too large", "protein is too large",
+      "failed to read hmmer3 profile", "too may partitions", "too many transitions", "not enough memory",
+      "failed to open DB file", "failed to open HMM file", "failed to open temporary file", "truncated file path",
+      "failed to unpack DP", "failed to pack DP", "failed to unpack nuclt dist", "failed to pack nuclt dist",
+      "failed to set transition", "failed to add state", "failed to reset DP", "failed to get file stat",
+      "failed to open file", "file is too large", "path is too long", "failed to reset task",
+      "failed to create new task", "failed to setup task", "failed to write product", "invalid partition",
+      "accession string is too long", "too many threads", "failed to create temporary file", "failed to flush file",
+      "failed to create directory", "wrong file format", "failed to remove directory", "failed to remove file",
+      "must set gencode first", "invalid gencode id", "dialing to hmmer daemon failed",
+      "failed to put a task to the hmmer daemon", "failed to pop a task from the hmmer daemon",
+      "failed to pack hmmer result", "reached maximum number of retries on hmmer daemon",
+      "failed to warmup hmmer daemon", "invalid sequence letter (neither DNA nor RNA alphabet)",
+      "failed to open file descriptor", "failed to make temporary file", "abc string is too long",
+      "consensus string is too long", nullptr /* DCP_ENOTDIALED has no message in the reference */,
+      "number of core nodes is too long", "invalid state", "invalid size", "unexpected end of file",
+      "unexpected end of nodes", "unsupported database version", "not a database file", "invalid state id",
+      "unsupported nucleotide (must be either DNA or RNA)", "database is DNA but sequence is RNA",
+      "database is RNA but sequence is DNA", "nucleotide sequence cannot have both U and T", "failed to find hit",
+      "failed to open file", "failed to close file", "failed to duplicate descriptor", "too many proteins",
+      "invalid number of proteins",
+  };
+  int const n = (int)(sizeof(msg) / sizeof(msg[0]));
+  if (code > 0 && code < n) return msg[code];
+  static thread_local char unknown[32];
+  snprintf(unknown, sizeof unknown, "unknown error #%d", code);
+  return unknown;
+}

@@ -1,0 +1,52 @@
+// host_logic.h -- the scalar host-side pieces around the DP (parameters in,
+// paths out).  Each function names the reference code it stands in for.
+#pragma once
+#include "dcp_types.h"
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+// c-core/xtrans.c:21-68: special transitions of a window whose amino length is
+// seq_size, negated into DP costs, in enum extr_trans_id order.
+void dcp_xtrans(int seq_size, bool multi_hits, bool hmmer3_compat, float xt[DCP_NUM_XTRANS]);
+
+// c-core/protein.c:353-394 (protein_setup_viterbi): node-major log-probs ->
+// DP cost arrays padded to Kp columns with +inf.  trans[8][Kp], match[1364][Kp].
+void dcp_setup_profile(int K, int Kp, float const *node_trans, float const *node_emission, float const *BMk,
+                       float const *null_lprob, float const *bg_lprob, float *trans, float *match, float *null_cost,
+                       float *bg_cost);
+
+// c-core/sequence.c:15-45 (uppercase + disambiguate, c-core/disambiguate.c:37-86)
+// followed by the A,C,G,T/U -> 0..3 indexing imm_eseq applies.  0 or DCP_E*.
+int dcp_encode_sequence(char const *data, int64_t n, uint8_t *out);
+
+// c-core/trellis.c:147-167 (trellis_unzip) with previous_state/emission_size
+// (:51-113).  Appends (state_id, seqsize) steps in path order.  0 or DCP_E*.
+int dcp_unzip(int K, int L, uint32_t const *xnodes, uint16_t const *nodes, std::vector<int32_t> &state_ids,
+              std::vector<int32_t> &seqsizes);
+
+// c-core/state.c:46-90
+void dcp_state_name(int state_id, char name[8]);
+bool dcp_state_is_mute(int state_id); // c-core/state.c:36-43
+
+// c-core/thread.c:130-166: the one hit of a window spans from the first B to
+// the last E of its path.  Returns false when the path holds no B.
+struct DcpHit
+{
+  int hit_start, hit_stop; // window-relative [start, stop)
+  int begin_step, end_step; // path steps [B, one past the last E)
+  int last_hit_pos;         // what window_set_last_hit_position receives
+};
+bool dcp_find_hit(std::vector<int32_t> const &state_ids, std::vector<int32_t> const &seqsizes, DcpHit &hit);
+
+// c-core/window.c:7-37
+struct DcpWindow
+{
+  int core_size, seq_size;
+  int start = -1, stop = 0, idx = -1, last_hit_pos = -1;
+  DcpWindow(int seq_size_, int core_size_) : core_size(core_size_), seq_size(seq_size_) {}
+  bool next();
+};
+
+// c-core/lrt.h:6-9
+inline float dcp_lrt(float null_loglik, float alt_loglik) { return -2 * (null_loglik - alt_loglik); }

@@ -1,0 +1,132 @@
+// lane_ops_gpu.h -- per-lane vocabulary of the Viterbi kernels on gfx950 (wave64).
+//
+// viterbi_body.h is written against this small set of names so that the very
+// same source can be instantiated a second time by tests/emul/ with 64-wide
+// array types (a lock-step wave emulator used only to unit-test the kernel
+// logic on a machine without a GPU).  Here every "lane" type is the plain
+// scalar a HIP thread holds, and the cross-lane operations are DPP / readlane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DCP_FN __device__ __forceinline__
+#define DCP_WAVE 64
+
+typedef float lf;    // one fp32 per lane
+typedef uint32_t lu; // one u32 per lane
+typedef bool lm;     // one predicate per lane
+
+DCP_FN lf lf_splat(float x) { return x; }
+DCP_FN lu lu_splat(uint32_t x) { return x; }
+DCP_FN lf lmin(lf a, lf b) { return __builtin_fminf(a, b); }
+DCP_FN lf lmin3(lf a, lf b, lf c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+DCP_FN lm llt(lf a, lf b) { return a < b; }
+DCP_FN lm llt_u(lu a, lu b) { return a < b; }
+DCP_FN lm leq(lf a, lf b) { return a == b; }
+DCP_FN lm lequ(lu a, lu b) { return a == b; }
+DCP_FN lm land(lm a, lm b) { return a && b; }
+DCP_FN lm lor(lm a, lm b) { return a || b; }
+DCP_FN lm lnot(lm a) { return !a; }
+DCP_FN lf lsel(lm m, lf a, lf b) { return m ? a : b; }
+DCP_FN lu lselu(lm m, lu a, lu b) { return m ? a : b; }
+DCP_FN lu lminu(lu a, lu b) { return a < b ? a : b; }
+DCP_FN lu lmaxu(lu a, lu b) { return a > b ? a : b; }
+
+// lane index inside the wave, 0..63
+DCP_FN lu lane_ids() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// lane e receives x of lane e-1; lane 0 receives `fill` (DPP wave_shr:1, the
+// 64-lane analogue of shift() in c-core/intrinsics.h:95-106)
+DCP_FN lf lane_shift_up(lf x, float fill)
+{
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
+}
+
+// min over the 64 lanes, returned to every lane (uniform).  DPP row_shr 1,2,4,8
+// then row_bcast 15 / 31; lanes with no source keep their own value.  hipcc adds
+// no wait states inside asm, so the two required between a VALU write and a DPP
+// read of the same VGPR are written out.
+DCP_FN float wave_min(lf v)
+{
+  asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+DCP_FN uint32_t wave_minu(lu v)
+{
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+DCP_FN bool wave_any(lm m) { return __builtin_amdgcn_ballot_w64(m) != 0ull; }
+DCP_FN uint64_t wave_ballot(lm m) { return __builtin_amdgcn_ballot_w64(m); }
+DCP_FN float read_lane(lf x, int lane)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+DCP_FN uint32_t read_laneu(lu x, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x, lane); }
+
+// ---- memory -------------------------------------------------------------------
+// Each lane owns Q consecutive profile positions k = lane*Q + q; a padded row of
+// Kp = 64*Q floats is therefore read as one coalesced dword x Q load per lane.
+template <int Q> DCP_FN void load_q(float const *__restrict__ row, lu lane, lf (&out)[Q]);
+template <> DCP_FN void load_q<1>(float const *__restrict__ row, lu lane, lf (&out)[1]) { out[0] = row[lane]; }
+template <> DCP_FN void load_q<2>(float const *__restrict__ row, lu lane, lf (&out)[2])
+{
+  float2 v = reinterpret_cast<float2 const *>(row)[lane];
+  out[0] = v.x;
+  out[1] = v.y;
+}
+template <> DCP_FN void load_q<3>(float const *__restrict__ row, lu lane, lf (&out)[3])
+{
+  // 12-byte elements: dwordx3 (the struct keeps 4-byte alignment)
+  struct f3 { float x, y, z; };
+  f3 v = reinterpret_cast<f3 const *>(row)[lane];
+  out[0] = v.x;
+  out[1] = v.y;
+  out[2] = v.z;
+}
+template <> DCP_FN void load_q<4>(float const *__restrict__ row, lu lane, lf (&out)[4])
+{
+  float4 v = reinterpret_cast<float4 const *>(row)[lane];
+  out[0] = v.x;
+  out[1] = v.y;
+  out[2] = v.z;
+  out[3] = v.w;
+}
+
+// trellis node words of one row: positions k = lane*Q + q < K
+template <int Q> DCP_FN void store_nodes_q(uint16_t *__restrict__ row, int K, lu lane, lu const (&w)[Q])
+{
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+  {
+    int k = (int)lane * Q + q;
+    if (k < K) row[k] = (uint16_t)w[q];
+  }
+}
+
+// a store done by exactly one lane of the wave
+DCP_FN void store_u32_lane0(uint32_t *p, lu lane, uint32_t v)
+{
+  if (lane == 0) *p = v;
+}
+DCP_FN void store_f32_lane0(float *p, lu lane, float v)
+{
+  if (lane == 0) *p = v;
+}

@@ -1,0 +1,513 @@
+// viterbi_body.h -- the quasi-codon Viterbi recurrences, one wavefront per
+// (profile x window) problem, written against the lane vocabulary of
+// lane_ops_gpu.h (tests/emul/ re-instantiates it with 64-wide arrays).
+//
+// Layout: lane e of the wave owns the Q consecutive profile positions
+// k = e*Q + q (the reference's striping k = e*Q + q, c-core/viterbi.c:220-221,
+// with 64 lanes instead of 4/8/16).  Rows l = 1..L are sequential (B of row l
+// needs E of row l, c-core/viterbi.c:582); the five emission lengths t = 1..5 of
+// a row and the K positions are the parallel work.
+//
+//   CostWave<Q>  viterbi_null + viterbi_cost (c-core/viterbi.c:696-724): scores only.
+//   PathWave<Q>  viterbi_path (c-core/viterbi.c:726-732): back-pointers, pass by
+//                pass exactly as the reference orders its strict-< updates.
+#pragma once
+#include "dcp_types.h"
+
+#ifndef DCP_FN
+#error "include a lane_ops_*.h before viterbi_body.h"
+#endif
+
+#define DCP_INF (__builtin_inff())
+
+// ring slot of row l-t when row l has phase P = l % 5
+#define DCP_SL(P, t) (((P) + 5 - (t)) % 5)
+
+DCP_FN void dcp_unpack_codes(uint4 cr, unsigned (&c)[5])
+{
+  c[0] = cr.x & 0xffffu;
+  c[1] = cr.x >> 16;
+  c[2] = cr.y & 0xffffu;
+  c[3] = cr.y >> 16;
+  c[4] = cr.z & 0xffffu;
+}
+
+// =============================================================================
+// Scores only.  Only minima matter here, and fp32 min is exact and rounding is
+// monotone, so min_i((x_i + t_i) + m) == (min_i (x_i + t_i)) + m bit for bit.
+// That lets every finished row z be folded ONCE into
+//     Mpre_z[k] = min(B_z+BM[k], M_z[k-1]+MM[k], I_z[k-1]+IM[k], D_z[k-1]+DM[k])
+//     Ipre_z[k] = min(I_z[k]+II[k], M_z[k]+MI[k])
+// and row l then needs only  M_l[k] = min_t (Mpre_{l-t}[k] + match[c_t][k]),
+// I_l[k] = min_t (Ipre_{l-t}[k] + bg[c_t])  -- the same fp32 values the reference
+// gets from c-core/viterbi.c:526-536, in 35 instead of 120 VALU ops per cell.
+// The four scalar chains N, J, C (c-core/viterbi.c:492-502) and the null model R
+// (:713) all have the shape X_l = min_t(Xpre_{l-t} + null[c_t]); they ride in
+// lanes 0..3 of one register.
+// E_l = min_k M_l[k]: the D_l[k] candidates of c-core/viterbi.c:541 are each
+// some M_l[j] plus non-negative delete costs (costs are -log-probabilities), so
+// they never lower the minimum.
+// =============================================================================
+template <int Q> struct CostWave
+{
+  lf BM[Q], MM[Q], MI[Q], MD[Q], IM[Q], II[Q], DM[Q], DD[Q];
+  lf Mpre[5][Q], Ipre[5][Q], Spre[5];
+  lf em[5][Q];
+  lf sa, sb;
+  lf X;
+  float nil[5], bgv[5];
+  float NB, EB, JB, ET, CT, RR;
+  float E;
+  lu lane;
+  float const *__restrict__ match;
+  float const *__restrict__ nullc;
+  float const *__restrict__ bgc;
+  uint4 const *__restrict__ codes;
+  int Kp;
+
+  DCP_FN void prefetch(int l)
+  {
+    unsigned c[5];
+    dcp_unpack_codes(codes[l], c);
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+    {
+      nil[t] = nullc[c[t]];
+      bgv[t] = bgc[c[t]];
+      load_q<Q>(match + (size_t)c[t] * (size_t)Kp, lane, em[t]);
+    }
+  }
+
+  DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, uint4 const *__restrict__ code_rows,
+                   float const *__restrict__ xt)
+  {
+    lane = lane_ids();
+    match = pool + pf.match_off;
+    nullc = pool + pf.null_off;
+    bgc = pool + pf.bg_off;
+    codes = code_rows;
+    Kp = pf.Kp;
+    float const *__restrict__ trans = pool + pf.trans_off;
+    load_q<Q>(trans + DCP_BM * Kp, lane, BM);
+    load_q<Q>(trans + DCP_MM * Kp, lane, MM);
+    load_q<Q>(trans + DCP_MI * Kp, lane, MI);
+    load_q<Q>(trans + DCP_MD * Kp, lane, MD);
+    load_q<Q>(trans + DCP_IM * Kp, lane, IM);
+    load_q<Q>(trans + DCP_II * Kp, lane, II);
+    load_q<Q>(trans + DCP_DM * Kp, lane, DM);
+    load_q<Q>(trans + DCP_DD * Kp, lane, DD);
+    NB = xt[DCP_NB];
+    EB = xt[DCP_EB];
+    JB = xt[DCP_JB];
+    ET = xt[DCP_ET];
+    CT = xt[DCP_CT];
+    RR = xt[DCP_RR];
+    float const SN = xt[DCP_SN], SB = xt[DCP_SB];
+    lm const l0 = lequ(lane, lu_splat(0)), l1 = lequ(lane, lu_splat(1));
+    lm const l2 = lequ(lane, lu_splat(2)), l3 = lequ(lane, lu_splat(3));
+    lf const inf = lf_splat(DCP_INF);
+    // lane: 0 = N, 1 = J, 2 = C, 3 = R.  Xpre = min(E + sa, X + sb)
+    sa = lsel(l1, lf_splat(xt[DCP_EJ]), lsel(l2, lf_splat(xt[DCP_EC]), inf));
+    sb = lsel(l0, lf_splat(xt[DCP_NN]),
+              lsel(l1, lf_splat(xt[DCP_JJ]), lsel(l2, lf_splat(xt[DCP_CC]), lsel(l3, lf_splat(RR), inf))));
+    // row 0 (c-core/viterbi.c:471-473, :703): S = 0, B = SB, R = -RR, rest +inf
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+    {
+      Spre[s] = inf;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+      {
+        Mpre[s][q] = inf;
+        Ipre[s][q] = inf;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) Mpre[0][q] = lf_splat(SB) + BM[q];
+    Spre[0] = lsel(l0, lf_splat(0.0f + SN), lsel(l3, lf_splat(-RR + RR), inf));
+    X = lsel(l3, lf_splat(-RR), inf);
+    E = DCP_INF;
+  }
+
+  template <int P> DCP_FN void row(int l, int L)
+  {
+    lf M[Q], I[Q], D[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      M[q] = lmin3(lmin3(Mpre[DCP_SL(P, 5)][q] + em[4][q], Mpre[DCP_SL(P, 4)][q] + em[3][q],
+                         Mpre[DCP_SL(P, 3)][q] + em[2][q]),
+                   Mpre[DCP_SL(P, 2)][q] + em[1][q], Mpre[DCP_SL(P, 1)][q] + em[0][q]);
+      I[q] = lmin3(lmin3(Ipre[DCP_SL(P, 5)][q] + bgv[4], Ipre[DCP_SL(P, 4)][q] + bgv[3],
+                         Ipre[DCP_SL(P, 3)][q] + bgv[2]),
+                   Ipre[DCP_SL(P, 2)][q] + bgv[1], Ipre[DCP_SL(P, 1)][q] + bgv[0]);
+    }
+    X = lmin3(lmin3(Spre[DCP_SL(P, 5)] + nil[4], Spre[DCP_SL(P, 4)] + nil[3], Spre[DCP_SL(P, 3)] + nil[2]),
+              Spre[DCP_SL(P, 2)] + nil[1], Spre[DCP_SL(P, 1)] + nil[0]);
+
+    // emissions of this row are consumed: fetch the next row's behind the rest
+    if (l < L) prefetch(l + 1);
+
+    // D_l[k] = min(M_l[k-1] + MD[k], D_l[k-1] + DD[k])  (c-core/viterbi.c:538,553-580)
+    lf const Msh0 = lane_shift_up(M[Q - 1], DCP_INF);
+    D[0] = Msh0 + MD[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
+    // carries across lanes, repeated until no lane improves (the reference's
+    // lazy D->D loop, c-core/viterbi.c:569-580)
+    lf x = lane_shift_up(D[Q - 1], DCP_INF) + DD[0];
+    while (wave_any(llt(x, D[0])))
+    {
+      D[0] = lmin(D[0], x);
+#pragma unroll
+      for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+      x = lane_shift_up(D[Q - 1], DCP_INF) + DD[0];
+    }
+
+    lf m = M[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q) m = lmin(m, M[q]);
+    E = wave_min(m);
+    float const N = read_lane(X, 0);
+    float const J = read_lane(X, 1);
+    float const B = __builtin_fminf(__builtin_fminf(N + NB, E + EB), J + JB); // c-core/viterbi.c:495-496,582-583
+
+    // fold row l into the ring (slot P held row l-5, no longer needed)
+    lf const Ish0 = lane_shift_up(I[Q - 1], DCP_INF);
+    lf const Dsh0 = lane_shift_up(D[Q - 1], DCP_INF);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      lf const Ml = q ? M[q ? q - 1 : 0] : Msh0;
+      lf const Il = q ? I[q ? q - 1 : 0] : Ish0;
+      lf const Dl = q ? D[q ? q - 1 : 0] : Dsh0;
+      Mpre[P][q] = lmin3(lf_splat(B) + BM[q], Ml + MM[q], lmin(Il + IM[q], Dl + DM[q]));
+      Ipre[P][q] = lmin(I[q] + II[q], M[q] + MI[q]);
+    }
+    Spre[P] = lmin(lf_splat(E) + sa, X + sb);
+  }
+
+  // out[0] = viterbi_null(), out[1] = viterbi_cost()
+  DCP_FN void run(int L, float *out)
+  {
+    if (L > 0) prefetch(1);
+    int l = 1;
+    for (; l + 4 <= L; l += 5)
+    {
+      row<1>(l, L);
+      row<2>(l + 1, L);
+      row<3>(l + 2, L);
+      row<4>(l + 3, L);
+      row<0>(l + 4, L);
+    }
+    if (l <= L) row<1>(l++, L);
+    if (l <= L) row<2>(l++, L);
+    if (l <= L) row<3>(l++, L);
+    if (l <= L) row<4>(l++, L);
+    float const C = read_lane(X, 2);
+    float const R = read_lane(X, 3);
+    float const T = L > 0 ? __builtin_fminf(E + ET, C + CT) : DCP_INF; // c-core/viterbi.c:585-586,599
+    store_f32_lane0(out + 0, lane, R);
+    store_f32_lane0(out + 1, lane, T);
+  }
+};
+
+// =============================================================================
+// Back-pointers.  Pointers depend on the ORDER of the reference's strict-<
+// updates whenever two candidates tie exactly in fp32, so this pass keeps the
+// reference's structure: for t = min(5,l)..1, each candidate as (x + trans) + emis,
+// BM,MM,IM,DM / II,MI / MD then DD; E recomputed per pass.  Pointers are held
+// directly as trellis fields (c-core/viterbi.c:631-694, c-core/trellis.h:42-56).
+// =============================================================================
+#define DCP_UPD(cur, ptr, val, newptr)                                         \
+  do                                                                           \
+  {                                                                            \
+    lf const v_ = (val);                                                       \
+    (ptr) = lselu(llt(v_, (cur)), lu_splat(newptr), (ptr));                    \
+    (cur) = lmin((cur), v_);                                                   \
+  } while (0)
+
+#define DCP_UPDS(cur, ptr, val, newptr)                                        \
+  do                                                                           \
+  {                                                                            \
+    float const v_ = (val);                                                    \
+    if (v_ < (cur)) (ptr) = (newptr);                                          \
+    (cur) = __builtin_fminf((cur), v_);                                        \
+  } while (0)
+
+template <int Q> struct PathWave
+{
+  lf BM[Q], MM[Q], MI[Q], MD[Q], IM[Q], II[Q], DM[Q], DD[Q];
+  // ring of the five previous rows; *sh = value of position k-1 for q = 0
+  lf M[5][Q], I[5][Q], D[5][Q], Msh[5], Ish[5], Dsh[5];
+  float S[5], N[5], B[5], J[5], E[5], C[5];
+  float xt[DCP_NUM_XTRANS];
+  lu lane;
+  int K, Kp;
+  float const *__restrict__ match;
+  float const *__restrict__ nullc;
+  float const *__restrict__ bgc;
+  uint4 const *__restrict__ codes;
+  uint32_t *__restrict__ xnodes;
+  uint16_t *__restrict__ nodes;
+
+  DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, uint4 const *__restrict__ code_rows,
+                   float const *__restrict__ xtp, uint32_t *__restrict__ xn, uint16_t *__restrict__ nd)
+  {
+    lane = lane_ids();
+    K = pf.K;
+    Kp = pf.Kp;
+    match = pool + pf.match_off;
+    nullc = pool + pf.null_off;
+    bgc = pool + pf.bg_off;
+    codes = code_rows;
+    xnodes = xn;
+    nodes = nd;
+    float const *__restrict__ trans = pool + pf.trans_off;
+    load_q<Q>(trans + DCP_BM * Kp, lane, BM);
+    load_q<Q>(trans + DCP_MM * Kp, lane, MM);
+    load_q<Q>(trans + DCP_MI * Kp, lane, MI);
+    load_q<Q>(trans + DCP_MD * Kp, lane, MD);
+    load_q<Q>(trans + DCP_IM * Kp, lane, IM);
+    load_q<Q>(trans + DCP_II * Kp, lane, II);
+    load_q<Q>(trans + DCP_DM * Kp, lane, DM);
+    load_q<Q>(trans + DCP_DD * Kp, lane, DD);
+#pragma unroll
+    for (int i = 0; i < DCP_NUM_XTRANS; ++i) xt[i] = xtp[i];
+    lf const inf = lf_splat(DCP_INF);
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+    {
+      S[s] = N[s] = B[s] = J[s] = E[s] = C[s] = DCP_INF;
+      Msh[s] = Ish[s] = Dsh[s] = inf;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) M[s][q] = I[s][q] = D[s][q] = inf;
+    }
+    S[0] = 0.0f; // c-core/viterbi.c:471-473
+    B[0] = xt[DCP_SB];
+    // row 0 of the trellis: every field 0 (before(), c-core/viterbi.c:602-629)
+    store_u32_lane0(xnodes, lane, 0u);
+    lu zero[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) zero[q] = lu_splat(0);
+    store_nodes_q<Q>(nodes, K, lane, zero);
+  }
+
+  // E back-pointer of the last pass: the reference reduces E over its own SIMD
+  // lanes (k = e*Qr + q), first-wins inside a lane in the order
+  // ME(0),DE(0)*,ME(1),DE(1),..,DE(0) and max(name,lane,q) across lanes
+  // (c-core/viterbi.c:540-541,555-558, c-core/intrinsics.h:151-160).  A single
+  // candidate equal to the minimum needs none of that.
+  DCP_FN uint32_t e_field(float v, lf const (&Ma)[Q], lf const (&Da)[Q], lf const (&Mbefore)[Q],
+                          lf const (&Dbefore)[Q])
+  {
+    if (!(v < DCP_INF)) return 0u;
+    lf const vv = lf_splat(v);
+    int total = 0;
+    lu field = lu_splat(0xffffffffu);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      lu const k2 = (lane * (uint32_t)Q + (uint32_t)q) * 2u;
+      lm const mM = leq(Ma[q], vv), mD = leq(Da[q], vv);
+      total += __builtin_popcountll(wave_ballot(mM)) + __builtin_popcountll(wave_ballot(mD));
+      field = lselu(mD, lminu(field, k2 + 1u), field);
+      field = lselu(mM, lminu(field, k2), field);
+    }
+    if (total == 1) return wave_minu(field);
+
+    // exact tie between distinct candidates: apply the reference's rule
+    int Qr = (K - 1) / DCP_REF_LANES + 1;
+    if (Qr < 2) Qr = 2; // c-core/viterbi.c:195-199
+    lf stale[Q];
+    lf const Mb0 = lane_shift_up(Mbefore[Q - 1], DCP_INF);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      lf const lastMb = q ? Mbefore[q ? q - 1 : 0] : Mb0;
+      stale[q] = lmin(Dbefore[q], lastMb + MD[q]);
+    }
+    uint32_t best = 0;
+    for (int er = 0; er < DCP_REF_LANES; ++er)
+    {
+      lu ord = lu_splat(0xffffffffu);
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+      {
+        lu const k = lane * (uint32_t)Q + (uint32_t)q;
+        lu const lo = lu_splat((uint32_t)(er * Qr));
+        lm const in = land(lnot(llt_u(k, lo)), llt_u(k, lo + (uint32_t)Qr));
+        lu const qr = k - lo;
+        lu const ordM = qr * 2u;
+        lu const ordD = lselu(lequ(qr, lu_splat(0)),
+                              lselu(leq(stale[q], vv), lu_splat(1u), lu_splat((uint32_t)(2 * Qr))), qr * 2u + 1u);
+        ord = lselu(land(in, leq(Ma[q], vv)), lminu(ord, ordM), ord);
+        ord = lselu(land(in, leq(Da[q], vv)), lminu(ord, ordD), ord);
+      }
+      uint32_t const w = wave_minu(ord);
+      if (w != 0xffffffffu)
+      {
+        uint32_t name, qr;
+        if (w == (uint32_t)(2 * Qr)) { name = 2u; qr = 0u; }
+        else { name = (w & 1u) ? 2u : 1u; qr = w >> 1; }
+        uint32_t const packed = (name << 28) | ((uint32_t)er << 24) | qr;
+        if (packed > best) best = packed;
+      }
+    }
+    uint32_t const q = best & 0x00ffffffu, e = (best >> 24) & 0xfu;
+    uint32_t const k = e * (uint32_t)Qr + q;
+    return 2u * k + ((best >> 28) == 2u ? 1u : 0u);
+  }
+
+  // one emission length t of row l; z = ring slot of row l-t
+  template <int T, int Z>
+  DCP_FN void pass(int l, lf (&Ma)[Q], lf (&Ia)[Q], lf (&Da)[Q], lu (&pM)[Q], lu (&pI)[Q], lu (&pD)[Q], float &Na,
+                   float &Ba, float &Ja, float &Ea, float &Ca, float &Ta, uint32_t &pN, uint32_t &pB, uint32_t &pJ,
+                   uint32_t &pE, uint32_t &pC, uint32_t &pT, unsigned code)
+  {
+    (void)l;
+    constexpr uint32_t u = (uint32_t)(T - 1);
+    float const nil = nullc[code];
+    float const bg = bgc[code];
+    lf em[Q];
+    load_q<Q>(match + (size_t)code * (size_t)Kp, lane, em);
+
+    DCP_UPDS(Na, pN, (S[Z] + xt[DCP_SN]) + nil, 0u + u); // c-core/viterbi.c:492-493
+    DCP_UPDS(Na, pN, (N[Z] + xt[DCP_NN]) + nil, 5u + u);
+    DCP_UPDS(Ba, pB, Na + xt[DCP_NB], 1u);               // :495-496 (S of a row > 0 is +inf)
+    DCP_UPDS(Ja, pJ, (E[Z] + xt[DCP_EJ]) + nil, 0u + u); // :498-499
+    DCP_UPDS(Ja, pJ, (J[Z] + xt[DCP_JJ]) + nil, 5u + u);
+    DCP_UPDS(Ca, pC, (E[Z] + xt[DCP_EC]) + nil, 0u + u); // :501-502
+    DCP_UPDS(Ca, pC, (C[Z] + xt[DCP_CC]) + nil, 5u + u);
+
+    lf Mbefore[Q], Dbefore[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      Mbefore[q] = Ma[q];
+      Dbefore[q] = Da[q];
+    }
+
+    lf const Bz = lf_splat(B[Z]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) // c-core/viterbi.c:526-536
+    {
+      lf const Ml = q ? M[Z][q ? q - 1 : 0] : Msh[Z];
+      lf const Il = q ? I[Z][q ? q - 1 : 0] : Ish[Z];
+      lf const Dl = q ? D[Z][q ? q - 1 : 0] : Dsh[Z];
+      DCP_UPD(Ma[q], pM[q], (Bz + BM[q]) + em[q], 0u + u);
+      DCP_UPD(Ma[q], pM[q], (Ml + MM[q]) + em[q], 5u + u);
+      DCP_UPD(Ma[q], pM[q], (Il + IM[q]) + em[q], 10u + u);
+      DCP_UPD(Ma[q], pM[q], (Dl + DM[q]) + em[q], 15u + u);
+      DCP_UPD(Ia[q], pI[q], (I[Z][q] + II[q]) + lf_splat(bg), 5u + u);
+      DCP_UPD(Ia[q], pI[q], (M[Z][q] + MI[q]) + lf_splat(bg), 0u + u);
+    }
+    lf const Mash0 = lane_shift_up(Ma[Q - 1], DCP_INF);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) // :538 and the stripe-0 repair :553-555
+    {
+      lf const lastMa = q ? Ma[q ? q - 1 : 0] : Mash0;
+      DCP_UPD(Da[q], pD[q], lastMa + MD[q], 0u);
+    }
+
+    lf m = lmin(Ma[0], Da[0]); // :540-541,556-558
+#pragma unroll
+    for (int q = 1; q < Q; ++q) m = lmin(m, lmin(Ma[q], Da[q]));
+    Ea = wave_min(m);
+    if (T == 1) pE = e_field(Ea, Ma, Da, Mbefore, Dbefore);
+
+    // D -> D: serial in k; done per lane, then carried across lanes until nothing
+    // improves (:561-580).  Strict-< updates make the pointers order-free.
+#pragma unroll
+    for (int q = 1; q < Q; ++q) DCP_UPD(Da[q], pD[q], Da[q - 1] + DD[q], 1u);
+    lf x = lane_shift_up(Da[Q - 1], DCP_INF) + DD[0];
+    while (wave_any(llt(x, Da[0])))
+    {
+      DCP_UPD(Da[0], pD[0], x, 1u);
+#pragma unroll
+      for (int q = 1; q < Q; ++q) DCP_UPD(Da[q], pD[q], Da[q - 1] + DD[q], 1u);
+      x = lane_shift_up(Da[Q - 1], DCP_INF) + DD[0];
+    }
+
+    DCP_UPDS(Ba, pB, Ea + xt[DCP_EB], 2u); // :582-583
+    DCP_UPDS(Ba, pB, Ja + xt[DCP_JB], 3u);
+    DCP_UPDS(Ta, pT, Ea + xt[DCP_ET], 0u); // :585-586
+    DCP_UPDS(Ta, pT, Ca + xt[DCP_CT], 1u);
+  }
+
+  template <int P> DCP_FN float row(int l)
+  {
+    lf const inf = lf_splat(DCP_INF);
+    lf Ma[Q], Ia[Q], Da[Q];
+    lu pM[Q], pI[Q], pD[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      Ma[q] = Ia[q] = Da[q] = inf;
+      pM[q] = pI[q] = pD[q] = lu_splat(0); // prev_core_state_init, c-core/viterbi.c:288-293
+    }
+    float Na = DCP_INF, Ba = DCP_INF, Ja = DCP_INF, Ea = DCP_INF, Ca = DCP_INF, Ta = DCP_INF;
+    uint32_t pN = 0, pB = 0, pJ = 0, pE = 0, pC = 0, pT = 0; // prev_extr_state_init, :295-306
+    unsigned c[5];
+    dcp_unpack_codes(codes[l], c);
+
+    if (l >= 5) pass<5, DCP_SL(P, 5)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[4]);
+    if (l >= 4) pass<4, DCP_SL(P, 4)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[3]);
+    if (l >= 3) pass<3, DCP_SL(P, 3)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[2]);
+    if (l >= 2) pass<2, DCP_SL(P, 2)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[1]);
+    pass<1, DCP_SL(P, 1)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[0]);
+
+    // after(): pack the row's pointers (c-core/viterbi.c:631-694)
+    store_u32_lane0(xnodes + l, lane, (pN << 0) | (pB << 4) | (pE << 6) | (pC << 21) | (pT << 25) | (pJ << 26));
+    lu w[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      lu const k = lane * (uint32_t)Q + (uint32_t)q;
+      lu word = pM[q];
+      word = word | lselu(lequ(k, lu_splat(0)), lu_splat(0), pD[q] << 5);              // node 0 has no D
+      word = word | lselu(llt_u(k + 1u, lu_splat((uint32_t)K)), pI[q] << 6, lu_splat(0)); // node K-1 has no I
+      w[q] = word;
+    }
+    store_nodes_q<Q>(nodes + (size_t)l * (size_t)K, K, lane, w);
+
+    // row l replaces row l-5 in the ring
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      M[P][q] = Ma[q];
+      I[P][q] = Ia[q];
+      D[P][q] = Da[q];
+    }
+    Msh[P] = lane_shift_up(Ma[Q - 1], DCP_INF);
+    Ish[P] = lane_shift_up(Ia[Q - 1], DCP_INF);
+    Dsh[P] = lane_shift_up(Da[Q - 1], DCP_INF);
+    S[P] = DCP_INF;
+    N[P] = Na;
+    B[P] = Ba;
+    J[P] = Ja;
+    E[P] = Ea;
+    C[P] = Ca;
+    return Ta;
+  }
+
+  // returns T of the last row (the path pass's own score; equals viterbi_cost)
+  DCP_FN float run(int L)
+  {
+    float T = DCP_INF;
+    int l = 1;
+    for (; l + 4 <= L; l += 5)
+    {
+      T = row<1>(l);
+      T = row<2>(l + 1);
+      T = row<3>(l + 2);
+      T = row<4>(l + 3);
+      T = row<0>(l + 4);
+    }
+    if (l <= L) T = row<1>(l++);
+    if (l <= L) T = row<2>(l++);
+    if (l <= L) T = row<3>(l++);
+    if (l <= L) T = row<4>(l++);
+    return T;
+  }
+};

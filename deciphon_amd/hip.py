@@ -1,0 +1,251 @@
+"""ctypes binding of include/deciphon_hip.h (the batched operator ABI)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TABLE_SIZE = 1364
+NUM_TRANS = 8
+NUM_XTRANS = 13
+
+
+class HipError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        msg = error_string(code)
+        super().__init__(f"deciphon error {code}: {msg}" + (f" ({detail})" if detail else ""))
+
+
+class Window(C.Structure):
+    """struct dcp_hip_window: [start, stop) of sequence `seq` against `profile`."""
+
+    _fields_ = [("profile", C.c_int32), ("seq", C.c_int32), ("start", C.c_int32), ("stop", C.c_int32)]
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "lib", "libdeciphon_hip.so")
+
+
+def load_library() -> C.CDLL:
+    """Loads the HIP library; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or make -C deciphon_amd/csrc); there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    L.dcp_hip_device_count.restype = i32
+    L.dcp_hip_new.argtypes = [i32]
+    L.dcp_hip_new.restype = vp
+    L.dcp_hip_del.argtypes = [vp]
+    L.dcp_hip_del.restype = None
+    L.dcp_hip_strerror.argtypes = [vp]
+    L.dcp_hip_strerror.restype = C.c_char_p
+    L.dcp_hip_add_profile.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(i32)]
+    L.dcp_hip_add_protein.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.POINTER(i32)]
+    L.dcp_hip_load_dcp.argtypes = [vp, C.c_char_p, i32, i32]
+    L.dcp_hip_num_profiles.argtypes = [vp]
+    L.dcp_hip_profile_core_size.argtypes = [vp, i32]
+    L.dcp_hip_profile_accession.argtypes = [vp, i32]
+    L.dcp_hip_profile_accession.restype = C.c_char_p
+    L.dcp_hip_commit_profiles.argtypes = [vp]
+    L.dcp_hip_clear_profiles.argtypes = [vp]
+    L.dcp_hip_clear_profiles.restype = None
+    L.dcp_hip_encode.argtypes = [C.c_char_p, C.c_int64, vp]
+    L.dcp_hip_set_sequences.argtypes = [vp, i32, vp, vp]
+    L.dcp_hip_set_mode.argtypes = [vp, i32, i32]
+    L.dcp_hip_set_xtrans_table.argtypes = [vp, i32, vp]
+    L.dcp_hip_xtrans.argtypes = [i32, i32, i32, vp]
+    L.dcp_hip_xtrans.restype = None
+    L.dcp_hip_cost.argtypes = [vp, i32, vp, vp, vp]
+    L.dcp_hip_cost_bench.argtypes = [vp, i32, vp, i32, i32, f32p, C.POINTER(C.c_double), vp, vp]
+    L.dcp_hip_path.argtypes = [vp, i32, vp]
+    L.dcp_hip_path_nsteps.argtypes = [vp, i32]
+    L.dcp_hip_path_steps.argtypes = [vp, i32, vp, vp]
+    L.dcp_hip_path_trellis.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.dcp_hip_path_score.argtypes = [vp, i32]
+    L.dcp_hip_path_score.restype = C.c_float
+    L.dcp_error_string.argtypes = [i32]
+    L.dcp_error_string.restype = C.c_char_p
+    _LIB = L
+    return L
+
+
+def error_string(code: int) -> str:
+    try:
+        s = load_library().dcp_error_string(int(code))
+    except ImportError:
+        return "?"
+    return s.decode() if s else ""
+
+
+def device_count() -> int:
+    return int(load_library().dcp_hip_device_count())
+
+
+def encode(data: str) -> np.ndarray:
+    """dcp_batch_add's normalisation of one nucleotide string -> indices 0..3."""
+    raw = data.encode()
+    out = np.zeros(len(raw), dtype=np.uint8)
+    rc = load_library().dcp_hip_encode(raw, len(raw), out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise HipError(rc)
+    return out
+
+
+def xtrans(seq_size: int, multi_hits: bool, hmmer3_compat: bool) -> np.ndarray:
+    out = np.zeros(NUM_XTRANS, dtype=np.float32)
+    load_library().dcp_hip_xtrans(int(seq_size), int(multi_hits), int(hmmer3_compat), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine:
+    """One GPU's worth of resident profiles and reads (struct dcp_hip)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.h = self.lib.dcp_hip_new(int(device))
+        if not self.h:
+            raise HipError(8, f"no usable HIP device {device}; there is no CPU fallback")
+        self._seq_lens = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dcp_hip_del(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc:
+            raise HipError(rc, self.lib.dcp_hip_strerror(self.h).decode())
+
+    # ---- profiles -------------------------------------------------------------
+    def add_profile(self, K: int, trans, match, null, bg) -> int:
+        trans, match, null, bg = _f32(trans), _f32(match), _f32(null), _f32(bg)
+        assert trans.shape == (NUM_TRANS, K) and match.shape == (TABLE_SIZE, K)
+        assert null.shape == (TABLE_SIZE,) and bg.shape == (TABLE_SIZE,)
+        idx = C.c_int(-1)
+        self._check(self.lib.dcp_hip_add_profile(self.h, K, _p(trans), _p(match), _p(null), _p(bg), C.byref(idx)))
+        return idx.value
+
+    def add_protein(self, K: int, node_trans, node_emission, BMk, null_lprob, bg_lprob) -> int:
+        a = [_f32(v) for v in (node_trans, node_emission, BMk, null_lprob, bg_lprob)]
+        assert a[0].shape == (K + 1, 7) and a[1].shape == (K + 1, TABLE_SIZE) and a[2].shape == (K,)
+        idx = C.c_int(-1)
+        self._check(self.lib.dcp_hip_add_protein(self.h, K, *[_p(v) for v in a], C.byref(idx)))
+        return idx.value
+
+    def load_dcp(self, path: str, first: int = 0, count: int = -1) -> None:
+        self._check(self.lib.dcp_hip_load_dcp(self.h, os.fsencode(path), first, count))
+
+    @property
+    def num_profiles(self) -> int:
+        return self.lib.dcp_hip_num_profiles(self.h)
+
+    def core_size(self, i: int) -> int:
+        return self.lib.dcp_hip_profile_core_size(self.h, i)
+
+    def accession(self, i: int) -> str:
+        s = self.lib.dcp_hip_profile_accession(self.h, i)
+        return s.decode() if s else ""
+
+    def commit(self) -> None:
+        self._check(self.lib.dcp_hip_commit_profiles(self.h))
+
+    def clear_profiles(self) -> None:
+        self.lib.dcp_hip_clear_profiles(self.h)
+
+    # ---- sequences ------------------------------------------------------------
+    def set_sequences(self, seqs) -> None:
+        """seqs: list of uint8 arrays of nucleotide indices 0..3."""
+        seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+        off = np.zeros(len(seqs) + 1, dtype=np.int64)
+        np.cumsum([len(s) for s in seqs], out=off[1:])
+        nt = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
+        nt = np.ascontiguousarray(nt)
+        self._check(self.lib.dcp_hip_set_sequences(self.h, len(seqs), _p(nt), _p(off)))
+        self._seq_lens = [len(s) for s in seqs]
+
+    def set_mode(self, multi_hits: bool = True, hmmer3_compat: bool = False) -> None:
+        self._check(self.lib.dcp_hip_set_mode(self.h, int(multi_hits), int(hmmer3_compat)))
+
+    def set_xtrans_table(self, table) -> None:
+        """table[rows][13]: caller-supplied special transitions for amino lengths 0..rows-1."""
+        t = _f32(table).reshape(-1, NUM_XTRANS)
+        self._check(self.lib.dcp_hip_set_xtrans_table(self.h, t.shape[0], _p(t)))
+
+    # ---- the DP ---------------------------------------------------------------
+    @staticmethod
+    def _windows(windows):
+        n = len(windows)
+        arr = (Window * max(n, 1))()
+        for i, w in enumerate(windows):
+            arr[i] = w if isinstance(w, Window) else Window(*w)
+        return n, arr
+
+    def cost(self, windows):
+        """-> (null_cost[n], alt_cost[n]): viterbi_null / viterbi_cost of every window."""
+        n, arr = self._windows(windows)
+        nul = np.zeros(n, dtype=np.float32)
+        alt = np.zeros(n, dtype=np.float32)
+        self._check(self.lib.dcp_hip_cost(self.h, n, arr, _p(nul), _p(alt)))
+        return nul, alt
+
+    def cost_bench(self, windows, warmup: int, reps: int):
+        """-> (ms per launch, cells per launch, null_cost, alt_cost), timed with HIP events."""
+        n, arr = self._windows(windows)
+        nul = np.zeros(n, dtype=np.float32)
+        alt = np.zeros(n, dtype=np.float32)
+        ms = C.c_float(0)
+        cells = C.c_double(0)
+        self._check(self.lib.dcp_hip_cost_bench(self.h, n, arr, warmup, reps, C.byref(ms), C.byref(cells), _p(nul),
+                                                _p(alt)))
+        return ms.value, cells.value, nul, alt
+
+    def path(self, windows):
+        """-> list of dicts(score, state_ids, seqsizes, xnodes, nodes) -- viterbi_path + trellis_unzip."""
+        n, arr = self._windows(windows)
+        self._check(self.lib.dcp_hip_path(self.h, n, arr))
+        out = []
+        for i in range(n):
+            ns = self.lib.dcp_hip_path_nsteps(self.h, i)
+            ids = np.zeros(ns, dtype=np.int32)
+            sizes = np.zeros(ns, dtype=np.int32)
+            self._check(self.lib.dcp_hip_path_steps(self.h, i, _p(ids), _p(sizes)))
+            xn, nd = C.c_void_p(), C.c_void_p()
+            self._check(self.lib.dcp_hip_path_trellis(self.h, i, C.byref(xn), C.byref(nd)))
+            w = arr[i]
+            L = w.stop - w.start
+            K = self.core_size(w.profile)
+            xnodes = np.ctypeslib.as_array(C.cast(xn, C.POINTER(C.c_uint32)), shape=(L + 1,)).copy()
+            nodes = np.ctypeslib.as_array(C.cast(nd, C.POINTER(C.c_uint16)), shape=((L + 1) * K,)).copy()
+            out.append(dict(score=np.float32(self.lib.dcp_hip_path_score(self.h, i)), state_ids=ids,
+                            seqsizes=sizes, xnodes=xnodes, nodes=nodes))
+        return out

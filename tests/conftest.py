@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from dcp_testlib import oracle
+
+    return oracle()
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """A deciphon_amd.Engine on cuda:0.  Fails loudly (no fallback) when the HIP
+    library or the device is missing."""
+    import deciphon_amd
+
+    eng = deciphon_amd.Engine(0)
+    yield eng
+    eng.close()

@@ -1,0 +1,131 @@
+"""Shared helpers of the test-suite: synthetic profiles/reads, the padded HBM layout
+of deciphon_amd/csrc/dcp_types.h restated in numpy, and loaders for the fixtures."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle.pyoracle import Oracle, Profile, RefLib  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+TABLE_SIZE = 1364
+INF = np.float32(np.inf)
+CODE_OFF = (0, 4, 20, 84, 340)
+
+
+class ProfileDev(C.Structure):
+    """struct DcpProfileDev (deciphon_amd/csrc/dcp_types.h)."""
+
+    _fields_ = [("K", C.c_int32), ("Kp", C.c_int32), ("Q", C.c_int32), ("W", C.c_int32),
+                ("match_off", C.c_int64), ("trans_off", C.c_int64), ("null_off", C.c_int64),
+                ("bg_off", C.c_int64)]
+
+
+def synth_profile(rng, K: int, quant=None, pinf: float = 0.0) -> Profile:
+    """Random profile in DP-cost space with the +inf structure protein_setup_viterbi
+    (c-core/protein.c:363-383) guarantees.  `quant` rounds every cost to a multiple of
+    it, which makes exact fp32 ties between distinct candidates common."""
+
+    def costs(shape, scale):
+        x = rng.random(shape).astype(np.float32) * np.float32(scale)
+        if quant:
+            x = np.round(x / quant) * quant
+        x = x.astype(np.float32)
+        if pinf:
+            x[rng.random(shape) < pinf] = INF
+        return x
+
+    trans = costs((8, K), 6.0)
+    trans[[1, 3, 4, 6, 7], 0] = INF  # MM MD IM DM DD of position 0
+    trans[[2, 5], K - 1] = INF  # MI II of position K-1
+    match = costs((TABLE_SIZE, K), 12.0)
+    null = costs((TABLE_SIZE,), 8.0)
+    bg = costs((TABLE_SIZE,), 8.0)
+    return Profile(K, np.ascontiguousarray(trans), np.ascontiguousarray(match), null, bg, f"SYN{K}")
+
+
+def choose_q(K: int) -> int:
+    return max(1, (K + 63) // 64)
+
+
+def pack_profile(prof: Profile, Q: int | None = None):
+    """-> (pool float32[...], ProfileDev) in the padded layout the kernels read."""
+    K = prof.K
+    Q = Q or choose_q(K)
+    Kp = 64 * Q
+    assert K <= Kp
+    match = np.full((TABLE_SIZE, Kp), INF, dtype=np.float32)
+    match[:, :K] = prof.match
+    trans = np.full((8, Kp), INF, dtype=np.float32)
+    trans[:, :K] = prof.trans
+    pool = np.concatenate([match.ravel(), trans.ravel(), prof.null, prof.bg]).astype(np.float32)
+    pd = ProfileDev(K, Kp, Q, 1, 0, match.size, match.size + trans.size, match.size + trans.size + TABLE_SIZE)
+    return pool, pd
+
+
+def code_rows(seq: np.ndarray) -> np.ndarray:
+    """DcpCodeRow[len+1]: row r holds the codes of the t-mers covering r-t..r-1."""
+    n = len(seq)
+    rows = np.zeros((n + 1, 8), dtype=np.uint16)
+    s = seq.astype(np.int64)
+    for t in range(1, 6):
+        if n < t:
+            break
+        idx = np.zeros(n - t + 1, dtype=np.int64)
+        for i in range(t):
+            idx = idx * 4 + s[i : n - t + 1 + i]
+        rows[t:, t - 1] = CODE_OFF[t - 1] + idx
+    return rows
+
+
+def random_seq(rng, n: int) -> np.ndarray:
+    return rng.integers(0, 4, size=n).astype(np.uint8)
+
+
+def read_fasta(path: str):
+    out, name, buf = [], None, []
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith(">"):
+                if name is not None:
+                    out.append((name, "".join(buf)))
+                name, buf = line[1:], []
+            elif line:
+                buf.append(line)
+    if name is not None:
+        out.append((name, "".join(buf)))
+    return out
+
+
+_oracle = None
+
+
+def oracle() -> Oracle:
+    global _oracle
+    if _oracle is None:
+        so = os.path.join(ROOT, "oracle", "libdcp_oracle.so")
+        src = os.path.join(ROOT, "oracle", "dcp_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+        _oracle = Oracle()
+    return _oracle
+
+
+def reflib():
+    """The reference's own viterbi.c (oracle/_ref), or None where it was not built."""
+    if not RefLib.available() and os.path.isdir("/root/reference/c-core"):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
+    return RefLib() if RefLib.available() else None
+
+
+def bits(x) -> int:
+    return int(np.float32(x).view(np.uint32))

@@ -1,0 +1,80 @@
+// lane_ops_emul.h -- TEST INFRASTRUCTURE ONLY.
+// A lock-step 64-lane emulation of the vocabulary in
+// deciphon_amd/csrc/lane_ops_gpu.h, so that deciphon_amd/csrc/viterbi_body.h
+// (the kernel logic itself, unchanged) can be unit-tested on a machine without a
+// GPU.  It is never part of the product library.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define DCP_FN inline
+#define DCP_WAVE 64
+
+struct uint4 { uint32_t x, y, z, w; };
+
+struct lf { float v[64]; };
+struct lu { uint32_t v[64]; };
+struct lm { bool v[64]; };
+
+#define EM_FOR for (int i_ = 0; i_ < 64; ++i_)
+
+inline lf lf_splat(float x) { lf r; EM_FOR r.v[i_] = x; return r; }
+inline lu lu_splat(uint32_t x) { lu r; EM_FOR r.v[i_] = x; return r; }
+inline lf operator+(lf a, lf b) { lf r; EM_FOR r.v[i_] = a.v[i_] + b.v[i_]; return r; }
+inline lf operator+(lf a, float b) { lf r; EM_FOR r.v[i_] = a.v[i_] + b; return r; }
+inline lf operator+(float a, lf b) { lf r; EM_FOR r.v[i_] = a + b.v[i_]; return r; }
+inline lf lmin(lf a, lf b) { lf r; EM_FOR r.v[i_] = fminf(a.v[i_], b.v[i_]); return r; }
+inline lf lmin3(lf a, lf b, lf c) { return lmin(lmin(a, b), c); }
+inline lm llt(lf a, lf b) { lm r; EM_FOR r.v[i_] = a.v[i_] < b.v[i_]; return r; }
+inline lm llt_u(lu a, lu b) { lm r; EM_FOR r.v[i_] = a.v[i_] < b.v[i_]; return r; }
+inline lm leq(lf a, lf b) { lm r; EM_FOR r.v[i_] = a.v[i_] == b.v[i_]; return r; }
+inline lm lequ(lu a, lu b) { lm r; EM_FOR r.v[i_] = a.v[i_] == b.v[i_]; return r; }
+inline lm land(lm a, lm b) { lm r; EM_FOR r.v[i_] = a.v[i_] && b.v[i_]; return r; }
+inline lm lor(lm a, lm b) { lm r; EM_FOR r.v[i_] = a.v[i_] || b.v[i_]; return r; }
+inline lm lnot(lm a) { lm r; EM_FOR r.v[i_] = !a.v[i_]; return r; }
+inline lf lsel(lm m, lf a, lf b) { lf r; EM_FOR r.v[i_] = m.v[i_] ? a.v[i_] : b.v[i_]; return r; }
+inline lu lselu(lm m, lu a, lu b) { lu r; EM_FOR r.v[i_] = m.v[i_] ? a.v[i_] : b.v[i_]; return r; }
+inline lu lminu(lu a, lu b) { lu r; EM_FOR r.v[i_] = a.v[i_] < b.v[i_] ? a.v[i_] : b.v[i_]; return r; }
+inline lu lmaxu(lu a, lu b) { lu r; EM_FOR r.v[i_] = a.v[i_] > b.v[i_] ? a.v[i_] : b.v[i_]; return r; }
+inline lu operator+(lu a, lu b) { lu r; EM_FOR r.v[i_] = a.v[i_] + b.v[i_]; return r; }
+inline lu operator+(lu a, uint32_t b) { lu r; EM_FOR r.v[i_] = a.v[i_] + b; return r; }
+inline lu operator-(lu a, lu b) { lu r; EM_FOR r.v[i_] = a.v[i_] - b.v[i_]; return r; }
+inline lu operator*(lu a, uint32_t b) { lu r; EM_FOR r.v[i_] = a.v[i_] * b; return r; }
+inline lu operator<<(lu a, int b) { lu r; EM_FOR r.v[i_] = a.v[i_] << b; return r; }
+inline lu operator|(lu a, lu b) { lu r; EM_FOR r.v[i_] = a.v[i_] | b.v[i_]; return r; }
+
+inline lu lane_ids() { lu r; EM_FOR r.v[i_] = (uint32_t)i_; return r; }
+
+inline lf lane_shift_up(lf x, float fill)
+{
+  lf r;
+  r.v[0] = fill;
+  for (int i = 1; i < 64; ++i) r.v[i] = x.v[i - 1];
+  return r;
+}
+
+inline float wave_min(lf v) { float m = v.v[0]; EM_FOR m = fminf(m, v.v[i_]); return m; }
+inline uint32_t wave_minu(lu v) { uint32_t m = v.v[0]; EM_FOR m = v.v[i_] < m ? v.v[i_] : m; return m; }
+inline bool wave_any(lm m) { EM_FOR if (m.v[i_]) return true; return false; }
+inline uint64_t wave_ballot(lm m) { uint64_t b = 0; EM_FOR if (m.v[i_]) b |= 1ull << i_; return b; }
+inline float read_lane(lf x, int lane) { return x.v[lane]; }
+inline uint32_t read_laneu(lu x, int lane) { return x.v[lane]; }
+
+template <int Q> inline void load_q(float const *row, lu lane, lf (&out)[Q])
+{
+  for (int q = 0; q < Q; ++q) EM_FOR out[q].v[i_] = row[lane.v[i_] * Q + q];
+}
+
+template <int Q> inline void store_nodes_q(uint16_t *row, int K, lu lane, lu const (&w)[Q])
+{
+  for (int q = 0; q < Q; ++q)
+    EM_FOR
+    {
+      int k = (int)lane.v[i_] * Q + q;
+      if (k < K) row[k] = (uint16_t)w[q].v[i_];
+    }
+}
+
+inline void store_u32_lane0(uint32_t *p, lu, uint32_t v) { *p = v; }
+inline void store_f32_lane0(float *p, lu, float v) { *p = v; }

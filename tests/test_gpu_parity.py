@@ -1,0 +1,188 @@
+"""GPU parity: the HIP path, called through the C ABI (include/deciphon_hip.h), against
+the CPU oracle on the same inputs and against goldens produced by the reference's own
+viterbi.c (tests/golden/make_golden.py).  Bit-exact: scores as fp32 bit patterns, every
+trellis word, every path step."""
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+from dcp_testlib import GOLDEN, bits, random_seq, read_fasta, synth_profile
+
+sys.path.insert(0, GOLDEN)
+from make_golden import MODES, synth_case_params, synth_xt  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads():
+    return read_fasta(os.path.join(GOLDEN, "consensus.fna")) + read_fasta(os.path.join(GOLDEN, "consensus_multi.fna"))
+
+
+def test_device_present():
+    import deciphon_amd
+
+    assert deciphon_amd.device_count() >= 1
+
+
+def test_synthetic_tie_rich_cases(engine, orc):
+    """240 small random profiles with costs quantised to multiples of 0.5..8 (exact fp32
+    ties between distinct candidates everywhere), K = 2..256, both window modes."""
+    g = np.load(os.path.join(GOLDEN, "synth_ties.npz"))
+    rng = np.random.default_rng(int(g["seed"]))
+    cases = []
+    for it in range(int(g["ncase"])):
+        K, L, quant, pinf, mh, h3 = synth_case_params(rng, it)
+        prof = synth_profile(rng, K, quant, pinf)
+        seq = random_seq(rng, L)
+        cases.append((it, K, L, quant, mh, h3, prof, seq))
+        assert K == int(g["K"][it]) and L == int(g["L"][it])
+    groups = {}
+    for c in cases:
+        groups.setdefault((c[3], c[4], c[5]), []).append(c)
+    for (quant, mh, h3), grp in groups.items():
+        engine.clear_profiles()
+        for c in grp:
+            engine.add_profile(c[6].K, c[6].trans, c[6].match, c[6].null, c[6].bg)
+        engine.commit()
+        engine.set_sequences([c[7] for c in grp])
+        engine.set_mode(bool(mh), bool(h3))
+        smax = max(max(c[2] // 3, 1) for c in grp)
+        table = np.zeros((smax + 1, 13), np.float32)
+        for s in range(1, smax + 1):
+            table[s] = synth_xt(orc, 3 * s, mh, h3, quant)
+        engine.set_xtrans_table(table)
+        wins = [(i, i, 0, c[2]) for i, c in enumerate(grp)]
+        nul, alt = engine.cost(wins)
+        paths = engine.path(wins)
+        for i, c in enumerate(grp):
+            it, K, L, _, _, _, prof, seq = c
+            xt = synth_xt(orc, L, mh, h3, quant)
+            assert bits(nul[i]) == bits(orc.null(prof, xt, seq)) == int(g["null_bits"][it]), (it, K, L)
+            assert bits(alt[i]) == bits(orc.cost(prof, xt, seq)) == int(g["alt_bits"][it]), (it, K, L)
+            score, xo, no = orc.path(prof, xt, seq)
+            assert bits(paths[i]["score"]) == bits(score), (it, K, L)
+            assert np.array_equal(paths[i]["xnodes"], xo), (it, K, L)
+            assert np.array_equal(paths[i]["nodes"], no), (it, K, L)
+            assert zlib.crc32(paths[i]["xnodes"].tobytes()) == int(g["xnodes_crc"][it])
+            assert zlib.crc32(paths[i]["nodes"].tobytes()) == int(g["nodes_crc"][it])
+            ids, sizes = orc.unzip(K, L, xo, no)
+            assert np.array_equal(paths[i]["state_ids"], ids) and np.array_equal(paths[i]["seqsizes"], sizes)
+    engine.set_xtrans_table(np.zeros((0, 13), np.float32))
+
+
+def test_minifam_consensus_against_reference_goldens(engine, orc):
+    """BASELINE config 1: minifam.dcp x the 8 consensus reads x the 4 mode combinations of
+    c-core/test_scan.c:15-16; expected values come from the reference's own viterbi.c."""
+    import deciphon_amd
+
+    g = np.load(os.path.join(GOLDEN, "minifam_consensus.npz"))
+    engine.clear_profiles()
+    engine.load_dcp(os.path.join(GOLDEN, "minifam.dcp"))
+    engine.commit()
+    assert engine.num_profiles == 3
+    assert [engine.core_size(i) for i in range(3)] == [173, 241, 162]
+    assert [engine.accession(i) for i in range(3)] == ["PF00742.20", "PF00696.29", "PF16620.6"]
+    reads = [deciphon_amd.encode(s) for _, s in _reads()]
+    engine.set_sequences(reads)
+    for mh, h3 in MODES:
+        engine.set_mode(bool(mh), bool(h3))
+        sel = np.nonzero((g["multi_hits"] == mh) & (g["hmmer3_compat"] == h3))[0]
+        wins = [(int(g["profile"][j]), int(g["read"][j]), 0, len(reads[int(g["read"][j])])) for j in sel]
+        nul, alt = engine.cost(wins)
+        for i, j in enumerate(sel):
+            assert bits(nul[i]) == int(g["null_bits"][j]), (mh, h3, wins[i])
+            assert bits(alt[i]) == int(g["alt_bits"][j]), (mh, h3, wins[i])
+        hit = [i for i, j in enumerate(sel) if np.isfinite(g["lrt"][j]) and g["lrt"][j] >= 0]
+        paths = engine.path([wins[i] for i in hit])
+        for p, i in zip(paths, hit):
+            j = sel[i]
+            assert bits(p["score"]) == int(g["alt_bits"][j])
+            assert zlib.crc32(p["xnodes"].tobytes()) == int(g["xnodes_crc"][j]), (mh, h3, wins[i])
+            assert zlib.crc32(p["nodes"].tobytes()) == int(g["nodes_crc"][j]), (mh, h3, wins[i])
+            a, b = int(g["path_off"][j]), int(g["path_off"][j + 1])
+            assert np.array_equal(p["state_ids"], g["path_ids"][a:b])
+            assert np.array_equal(p["seqsizes"], g["path_sizes"][a:b])
+
+
+def test_products_tsv_of_the_reference(engine, orc):
+    """The reference's committed scan output (control/tests/files/snap.dcs): lrt to the
+    printed precision, window/hit ranges and the state name + subsequence of every match."""
+    import deciphon_amd
+
+    engine.clear_profiles()
+    engine.load_dcp(os.path.join(GOLDEN, "minifam.dcp"))
+    engine.commit()
+    named = read_fasta(os.path.join(GOLDEN, "consensus.fna"))
+    reads = [deciphon_amd.encode(s) for _, s in named]
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    acc = {engine.accession(i): i for i in range(engine.num_profiles)}
+    rows = [line.rstrip("\n").split("\t") for line in open(os.path.join(GOLDEN, "products.tsv"))][1:]
+    assert len(rows) == 3
+    for row in rows:
+        seq_id, win, wstart, wstop, hit, hstart, hstop, profile, abc, lrt, _evalue, match = row
+        si, pi = int(seq_id), acc[profile]
+        w = (pi, si, int(wstart), int(wstop))
+        nul, alt = engine.cost([w])
+        assert f"{orc.lrt(-nul[0], -alt[0]):.1f}" == lrt
+        p = engine.path([w])[0]
+        h, _last = orc.hits(p["state_ids"], p["seqsizes"])
+        assert h is not None and (h[0], h[1]) == (int(hstart), int(hstop))
+        pos, got = h[0], []
+        for st, sz in zip(p["state_ids"][h[2] : h[3]], p["seqsizes"][h[2] : h[3]]):
+            got.append((named[si][1][int(wstart) + pos : int(wstart) + pos + sz], orc.state_name(st)))
+            pos += sz
+        want = [tuple(m.split(",")[:2]) for m in match.split(";")]
+        assert got == want
+
+
+def test_windows_inside_reads_and_ragged_batch(engine, orc):
+    """Windows that start mid-read (the t-mers before the window start must not leak in),
+    lengths 1..5 (fewer than five emission lengths), and profiles of every Q class in one call."""
+    rng = np.random.default_rng(99)
+    profs = [synth_profile(rng, K) for K in (2, 3, 64, 65, 128, 130, 192, 200, 256)]
+    engine.clear_profiles()
+    for p in profs:
+        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    engine.commit()
+    reads = [random_seq(rng, n) for n in (1, 2, 5, 17, 200, 333)]
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    wins = []
+    for pi in range(len(profs)):
+        for si, r in enumerate(reads):
+            n = len(r)
+            wins.append((pi, si, 0, n))
+            for _ in range(3):
+                a = int(rng.integers(0, n))
+                b = int(rng.integers(a + 1, n + 1))
+                wins.append((pi, si, a, b))
+            for L in (1, 2, 3, 4, 5):
+                if n >= L:
+                    wins.append((pi, si, n - L, n))
+    nul, alt = engine.cost(wins)
+    paths = engine.path(wins)
+    for i, (pi, si, a, b) in enumerate(wins):
+        seq = np.ascontiguousarray(reads[si][a:b])
+        xt = orc.xtrans(max((b - a) // 3, 1), True, False)
+        assert bits(nul[i]) == bits(orc.null(profs[pi], xt, seq)), wins[i]
+        assert bits(alt[i]) == bits(orc.cost(profs[pi], xt, seq)), wins[i]
+        score, xo, no = orc.path(profs[pi], xt, seq)
+        assert bits(paths[i]["score"]) == bits(score)
+        assert np.array_equal(paths[i]["xnodes"], xo) and np.array_equal(paths[i]["nodes"], no), wins[i]
+
+
+def test_empty_and_invalid_calls(engine):
+    import deciphon_amd
+
+    nul, alt = engine.cost([])
+    assert len(nul) == 0 and len(alt) == 0
+    with pytest.raises(deciphon_amd.HipError) as e:
+        engine.cost([(10 ** 6, 0, 0, 1)])
+    assert e.value.code == 8  # DCP_EFUNCUSE
+    with pytest.raises(deciphon_amd.HipError) as e:
+        engine.cost([(0, 0, 3, 3)])
+    assert e.value.code == 11  # DCP_EZEROSEQ
