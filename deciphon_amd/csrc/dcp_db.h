@@ -66,4 +66,4 @@ private:
 };
 
 // c-core/partition_size.c:13-16
-long dcp_partition_size(long nelems, long nparts, long idx);
+extern "C" long dcp_partition_size(long nelems, long nparts, long idx);

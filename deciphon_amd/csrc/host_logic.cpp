@@ -21,15 +21,20 @@ void dcp_xtrans(int seq_size, bool multi_hits, bool hmmer3_compat, float xt[DCP_
     q = 0.5f;
     log_q = (float)log(0.5);
   }
+  // C++ would pick the float overload of log() for a float argument; the reference
+  // is C, where log() is the double function, so widen explicitly.
   float const denom = L + 2 + q / (1 - q);
-  float const lp = (float)(log(L) - log(denom));
-  float const l1p = (float)(log(2 + q / (1 - q)) - log(denom));
-  float const lr = (float)(log(L) - log(L + 1));
+  float const two_q = 2 + q / (1 - q);
+  float const Lp1 = L + 1;
+  float const lp = (float)(log((double)L) - log((double)denom));
+  float const l1p = (float)(log((double)two_q) - log((double)denom));
+  float const lr = (float)(log((double)L) - log((double)Lp1));
 
   float NN = lp, CC = lp, JJ = lp;
   float const NB = l1p, CT = l1p, JB = l1p, RR = lr;
   float const EJ = log_q;
-  float const EC = (float)log(1 - q);
+  float const one_q = 1 - q;
+  float const EC = (float)log((double)one_q);
   if (hmmer3_compat) NN = CC = JJ = logf(1);
 
   // c-core/xtrans.c:53-68

@@ -1,0 +1,110 @@
+"""CPU: the kernel logic itself (deciphon_amd/csrc/viterbi_body.h, unchanged) instantiated
+on a lock-step 64-lane emulator (tests/emul/) and compared bit for bit with the oracle.
+This checks striping, the folded recurrences of the cost pass, the lazy D->D carries and
+the E tie rule without a GPU; the DPP/readlane lowering itself is only tested with -m gpu."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from dcp_testlib import GOLDEN, ROOT, bits, code_rows, pack_profile, random_seq, read_fasta, synth_profile
+from oracle.dcp_reader import read_dcp
+
+
+@pytest.fixture(scope="module")
+def em():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul")], check=True)
+    return C.CDLL(os.path.join(ROOT, "tests", "emul", "libdcp_emul.so"))
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def run_cost(em, prof, xt, seq):
+    pool, pd = pack_profile(prof)
+    rows = code_rows(seq)
+    xt16 = np.zeros(16, np.float32)
+    xt16[:13] = xt
+    out = np.zeros(2, np.float32)
+    assert em.emul_cost(_vp(pool), C.byref(pd), _vp(rows), len(seq), _vp(xt16), _vp(out)) == 0
+    return out
+
+
+def run_path(em, prof, xt, seq):
+    pool, pd = pack_profile(prof)
+    rows = code_rows(seq)
+    xt16 = np.zeros(16, np.float32)
+    xt16[:13] = xt
+    L = len(seq)
+    xn = np.zeros(L + 1, np.uint32)
+    nd = np.zeros((L + 1) * prof.K, np.uint16)
+    sc = C.c_float(0)
+    assert em.emul_path(_vp(pool), C.byref(pd), _vp(rows), L, _vp(xt16), _vp(xn), _vp(nd), C.byref(sc)) == 0
+    return np.float32(sc.value), xn, nd
+
+
+def test_code_rows_helper(orc):
+    seq = random_seq(np.random.default_rng(0), 40)
+    rows = code_rows(seq)
+    for r in range(1, 41):
+        for t in range(1, 6):
+            if r - t >= 0:
+                assert rows[r, t - 1] == orc.code(seq, r - t, t)
+
+
+def test_tie_rich_random_cases(em, orc):
+    rng = np.random.default_rng(7)
+    for it in range(400):
+        K = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 33, 63, 64, 65, 100, 128, 129, 173, 192, 193, 241, 256]))
+        quant = [None, 0.5, 1.0, 2.0, 4.0, 8.0][it % 6]
+        prof = synth_profile(rng, K, quant, [0, 0.05, 0.3][it % 3])
+        seq = random_seq(rng, int(rng.integers(1, 40)))
+        xt = orc.xtrans(max(len(seq) // 3, 1), it % 2, (it // 2) % 2)
+        if quant:
+            xt = (np.round(xt / quant) * quant).astype(np.float32)
+        out = run_cost(em, prof, xt, seq)
+        assert bits(out[0]) == bits(orc.null(prof, xt, seq)), (it, K)
+        assert bits(out[1]) == bits(orc.cost(prof, xt, seq)), (it, K)
+        score, xn, nd = run_path(em, prof, xt, seq)
+        s_o, xo, no = orc.path(prof, xt, seq)
+        assert bits(score) == bits(s_o)
+        assert np.array_equal(xn, xo) and np.array_equal(nd, no), (it, K, quant)
+
+
+def test_long_delete_runs_cross_many_lanes(em, orc):
+    """Cheap D->D and expensive everything else: delete runs span dozens of lanes, so the
+    lazy carry loop must iterate many times (worst case of c-core/viterbi.c:569-580)."""
+    rng = np.random.default_rng(3)
+    for K in (64, 130, 256):
+        prof = synth_profile(rng, K)
+        prof.trans[7, 1:] = np.float32(0.01)  # DD
+        prof.trans[3, 1:] = np.float32(0.02)  # MD
+        prof.trans[1, 1:] = np.float32(9.0)   # MM
+        prof.match[:, K // 2:] += np.float32(30.0)
+        seq = random_seq(rng, 25)
+        xt = orc.xtrans(8, True, False)
+        out = run_cost(em, prof, xt, seq)
+        assert bits(out[1]) == bits(orc.cost(prof, xt, seq))
+        score, xn, nd = run_path(em, prof, xt, seq)
+        s_o, xo, no = orc.path(prof, xt, seq)
+        assert bits(score) == bits(s_o) and np.array_equal(xn, xo) and np.array_equal(nd, no)
+        assert ((no >> 5) & 1).sum() > K  # plenty of D<-D pointers were taken
+
+
+def test_minifam_consensus_pairs(em, orc):
+    db = read_dcp(os.path.join(GOLDEN, "minifam.dcp"))
+    reads = [orc.encode(s) for _, s in read_fasta(os.path.join(GOLDEN, "consensus.fna"))]
+    for pi, ri in ((0, 0), (1, 1), (2, 2), (0, 1)):
+        prof = orc.setup_profile(db.proteins[pi])
+        seq = reads[ri]
+        xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+        out = run_cost(em, prof, xt, seq)
+        assert bits(out[0]) == bits(orc.null(prof, xt, seq)) and bits(out[1]) == bits(orc.cost(prof, xt, seq))
+    prof, seq = orc.setup_profile(db.proteins[2]), reads[2]
+    xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+    score, xn, nd = run_path(em, prof, xt, seq)
+    s_o, xo, no = orc.path(prof, xt, seq)
+    assert bits(score) == bits(s_o) and np.array_equal(xn, xo) and np.array_equal(nd, no)
