@@ -182,7 +182,7 @@ class RefLib:
         L.ref_cost.argtypes = [C.c_void_p, u8p, C.c_int]
         L.ref_cost.restype = C.c_float
         L.ref_path.argtypes = [C.c_void_p, u8p, C.c_int, u32p, u16p]
-        L.ref_bench.argtypes = [C.c_int, f32p, f32p, f32p, f32p, f32p, u8p, i64p, C.c_int, C.c_int, f32p]
+        L.ref_bench.argtypes = [C.c_int, f32p, f32p, f32p, f32p, f32p, u8p, i64p, C.c_int, C.c_int, C.c_int, f32p]
         L.ref_bench.restype = C.c_double
         self.h = C.c_void_p(L.ref_new())
         self.K = 0
@@ -222,10 +222,11 @@ class RefLib:
         assert rc == 0
         return xnodes, nodes
 
-    def bench(self, prof: Profile, xts: np.ndarray, seqs: np.ndarray, offsets: np.ndarray, nthreads: int):
+    def bench(self, prof: Profile, xts: np.ndarray, seqs: np.ndarray, offsets: np.ndarray, nthreads: int,
+              repeat: int = 1):
         nprob = len(offsets) - 1
         out = np.zeros(2 * nprob, dtype=np.float32)
         secs = self.lib.ref_bench(prof.K, prof.trans, prof.match, prof.null, prof.bg,
                                   np.ascontiguousarray(xts, dtype=np.float32), seqs,
-                                  np.ascontiguousarray(offsets, dtype=np.int64), nprob, nthreads, out)
+                                  np.ascontiguousarray(offsets, dtype=np.int64), nprob, nthreads, repeat, out)
         return secs, out.reshape(nprob, 2)

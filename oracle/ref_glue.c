@@ -208,7 +208,7 @@ int ref_path(void *p, uint8_t const *seq, int L, uint32_t *xnodes, uint16_t *nod
  * works of c-core/scan.c:188-208.  Returns seconds; scores go to out[2*nprob]. */
 double ref_bench(int K, float const *trans, float const *match, float const *null_cost,
                  float const *bg_cost, float const *xt /*[nprob][13]*/, uint8_t const *seqs,
-                 int64_t const *offsets /*[nprob+1]*/, int nprob, int nthreads, float *out)
+                 int64_t const *offsets /*[nprob+1]*/, int nprob, int nthreads, int repeat, float *out)
 {
   void **refs = malloc(sizeof(void *) * (size_t)nthreads);
   uint16_t **codes = malloc(sizeof(uint16_t *) * (size_t)nprob);
@@ -223,8 +223,9 @@ double ref_bench(int K, float const *trans, float const *match, float const *nul
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
-  for (int i = 0; i < nprob; ++i)
+  for (int j = 0; j < nprob * repeat; ++j)
   {
+    int i = j % nprob;
     struct ref *r = refs[omp_get_thread_num()];
     int L = (int)(offsets[i + 1] - offsets[i]);
     struct codes c = {codes[i]};

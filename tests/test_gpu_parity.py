@@ -184,5 +184,8 @@ def test_empty_and_invalid_calls(engine):
         engine.cost([(10 ** 6, 0, 0, 1)])
     assert e.value.code == 8  # DCP_EFUNCUSE
     with pytest.raises(deciphon_amd.HipError) as e:
-        engine.cost([(0, 0, 3, 3)])
+        engine.cost([(0, 0, 0, 0)])
     assert e.value.code == 11  # DCP_EZEROSEQ
+    with pytest.raises(deciphon_amd.HipError) as e:
+        engine.cost([(0, 0, 0, 10 ** 7)])
+    assert e.value.code == 8
