@@ -59,7 +59,7 @@ template <class T> struct DevBuf
 
 struct HostProfile
 {
-  int K, Kp, Q, W;
+  int K, Kp, Q, W, cls;
   int64_t pool_off; // floats
   std::string accession;
 };
@@ -78,6 +78,10 @@ struct dcp_hip
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  // one side stream per kernel class, so that the kernels of different
+  // classes (few problems each in small scans) share the GPU instead of queueing
+  hipStream_t qstream[DCP_NUM_CLASSES] = {nullptr};
+  hipEvent_t fork_ev = nullptr, join_ev[DCP_NUM_CLASSES] = {nullptr};
   std::string err;
 
   // profiles
@@ -130,8 +134,6 @@ int fail(dcp_hip *x, int rc, char const *what, hipError_t e = hipSuccess)
     if (e_ != hipSuccess) return fail((x), (rc), #call, e_);                   \
   } while (0)
 
-int choose_q(int K) { return (K + 63) / 64; }
-
 int ensure_xt(dcp_hip *x, int rows_needed)
 {
   if (!x->mode_set) return fail(x, DCP_EFUNCUSE, "dcp_hip_set_mode has not been called");
@@ -151,8 +153,8 @@ int ensure_xt(dcp_hip *x, int rows_needed)
 
 struct Staged
 {
-  std::vector<DcpProblem> problems; // sorted by (Q, profile)
-  int q_begin[DCP_MAX_Q + 2] = {0}; // problems of class Q are [q_begin[Q], q_begin[Q+1])
+  std::vector<DcpProblem> problems;       // sorted by (class, profile)
+  int c_begin[DCP_NUM_CLASSES + 1] = {0}; // problems of class c are [c_begin[c], c_begin[c+1])
   double cells = 0;
   size_t arena_bytes = 0;
 };
@@ -193,18 +195,18 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, bool with_trellis, Staged 
   }
   st.arena_bytes = arena;
   std::stable_sort(st.problems.begin(), st.problems.end(), [&](DcpProblem const &a, DcpProblem const &b) {
-    int qa = x->profiles[(size_t)a.profile].Q, qb = x->profiles[(size_t)b.profile].Q;
-    if (qa != qb) return qa < qb;
+    int ca = x->profiles[(size_t)a.profile].cls, cb = x->profiles[(size_t)b.profile].cls;
+    if (ca != cb) return ca < cb;
     return a.profile < b.profile;
   });
   int i = 0;
-  for (int q = 1; q <= DCP_MAX_Q; ++q)
+  for (int c = 0; c < DCP_NUM_CLASSES; ++c)
   {
-    st.q_begin[q] = i;
-    while (i < n && x->profiles[(size_t)st.problems[(size_t)i].profile].Q == q) ++i;
+    st.c_begin[c] = i;
+    while (i < n && x->profiles[(size_t)st.problems[(size_t)i].profile].cls == c) ++i;
   }
-  st.q_begin[DCP_MAX_Q + 1] = i;
-  if (i != n) return fail(x, DCP_ELARGECORESIZE, "profile longer than the single-wave kernels cover");
+  st.c_begin[DCP_NUM_CLASSES] = i;
+  if (i != n) return fail(x, DCP_ELARGECORESIZE, "profile outside every kernel class");
   int rc = ensure_xt(x, max_s + 1);
   if (rc) return rc;
   HIP_TRY(x, x->d_problems.reserve((size_t)std::max(n, 1)), DCP_ENOMEM);
@@ -215,34 +217,55 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, bool with_trellis, Staged 
   return 0;
 }
 
-DcpLaunch launch_args(dcp_hip *x, Staged const &st, int q)
+DcpLaunch launch_args(dcp_hip *x, Staged const &st, int c)
 {
   DcpLaunch a;
   a.pool = x->d_pool.p;
   a.profiles = x->d_profiles.p;
-  a.problems = x->d_problems.p + st.q_begin[q];
+  a.problems = x->d_problems.p + st.c_begin[c];
   a.code_rows = x->d_rows.p;
   a.xt_table = x->d_xt.p;
   a.out = x->d_out.p;
   a.arena = x->d_arena.p;
-  a.nprob = st.q_begin[q + 1] - st.q_begin[q];
+  a.nprob = st.c_begin[c + 1] - st.c_begin[c];
   a.stream = x->stream;
   return a;
 }
 
-int launch_cost_all(dcp_hip *x, Staged const &st)
+// Launches the path (or cost) kernels of every class present: the classes run
+// concurrently on their own streams, forked from and joined back into x->stream.
+int launch_all(dcp_hip *x, Staged const &st, bool path)
 {
-  for (int q = 1; q <= DCP_MAX_Q; ++q)
+  int classes = 0;
+  for (int c = 0; c < DCP_NUM_CLASSES; ++c) classes += st.c_begin[c + 1] > st.c_begin[c];
+  bool const fork = classes > 1;
+  if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
+  for (int c = 0; c < DCP_NUM_CLASSES; ++c)
   {
-    DcpLaunch a = launch_args(x, st, q);
-    HIP_TRY(x, dcp_launch_cost(q, a), DCP_EFUNCUSE);
+    DcpLaunch a = launch_args(x, st, c);
+    if (a.nprob <= 0) continue;
+    if (fork)
+    {
+      a.stream = x->qstream[c];
+      HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
+    }
+    HIP_TRY(x, path ? dcp_launch_path(c, a) : dcp_launch_cost(c, a), DCP_EFUNCUSE);
+    if (fork)
+    {
+      HIP_TRY(x, hipEventRecord(x->join_ev[c], a.stream), DCP_EFUNCUSE);
+      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
+    }
   }
   return 0;
 }
 
+int launch_cost_all(dcp_hip *x, Staged const &st) { return launch_all(x, st, false); }
+
 } // namespace
 
 extern "C" {
+
+void dcp_hip_del(struct dcp_hip *x);
 
 int dcp_hip_device_count(void)
 {
@@ -258,9 +281,16 @@ struct dcp_hip *dcp_hip_new(int device)
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   dcp_hip *x = new dcp_hip;
   x->device = device;
-  if (hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) != hipSuccess)
+  bool ok = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&x->fork_ev, hipEventDisableTiming) == hipSuccess;
+  for (int c = 0; ok && c < DCP_NUM_CLASSES; ++c)
   {
-    delete x;
+    ok = ok && hipStreamCreateWithFlags(&x->qstream[c], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&x->join_ev[c], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok)
+  {
+    dcp_hip_del(x);
     return nullptr;
   }
   x->seq_off.assign(1, 0);
@@ -272,11 +302,14 @@ void dcp_hip_del(struct dcp_hip *x)
 {
   if (!x) return;
   (void)hipSetDevice(x->device);
-  if (x->stream)
+  if (x->stream) (void)hipStreamSynchronize(x->stream);
+  for (int c = 0; c < DCP_NUM_CLASSES; ++c)
   {
-    (void)hipStreamSynchronize(x->stream);
-    (void)hipStreamDestroy(x->stream);
+    if (x->qstream[c]) (void)hipStreamDestroy(x->qstream[c]);
+    if (x->join_ev[c]) (void)hipEventDestroy(x->join_ev[c]);
   }
+  if (x->fork_ev) (void)hipEventDestroy(x->fork_ev);
+  if (x->stream) (void)hipStreamDestroy(x->stream);
   delete x;
 }
 
@@ -286,13 +319,13 @@ static int add_slot(dcp_hip *x, int K, char const *accession, float **trans, flo
                     int *index)
 {
   if (K < 1 || K > DCP_MODEL_MAX) return fail(x, DCP_ELARGECORESIZE, "core size out of range");
-  int const Q = choose_q(K);
-  if (Q > DCP_MAX_Q) return fail(x, DCP_ELARGECORESIZE, "core size beyond 64*DCP_MAX_Q not supported yet");
+  int const cls = dcp_class_of(K);
+  if (cls < 0) return fail(x, DCP_ELARGECORESIZE, "core size beyond DCP_MAX_CORE_SIZE (4096) is not supported yet");
   HostProfile hp;
   hp.K = K;
-  hp.Q = Q;
-  hp.W = 1;
-  hp.Kp = 64 * Q;
+  hp.cls = cls;
+  dcp_class_shape(cls, &hp.Q, &hp.W);
+  hp.Kp = 64 * hp.Q * hp.W;
   hp.pool_off = (int64_t)x->pool.size();
   hp.accession = accession ? accession : "";
   size_t const floats = (size_t)(DCP_TABLE_SIZE + DCP_NUM_TRANS) * hp.Kp + 2 * DCP_TABLE_SIZE;
@@ -558,11 +591,7 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
   if (n == 0) return 0;
   HIP_TRY(x, x->d_out.reserve((size_t)n), DCP_ENOMEM);
   HIP_TRY(x, x->d_arena.reserve(st.arena_bytes), DCP_ENOMEM);
-  for (int q = 1; q <= DCP_MAX_Q; ++q)
-  {
-    DcpLaunch a = launch_args(x, st, q);
-    HIP_TRY(x, dcp_launch_path(q, a), DCP_EFUNCUSE);
-  }
+  if ((rc = launch_all(x, st, true))) return rc;
   x->host_arena.resize(st.arena_bytes);
   std::vector<float> out((size_t)n);
   HIP_TRY(x, hipMemcpyAsync(x->host_arena.data(), x->d_arena.p, st.arena_bytes, hipMemcpyDeviceToHost, x->stream),

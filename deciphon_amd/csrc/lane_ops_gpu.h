@@ -81,6 +81,119 @@ DCP_FN float read_lane(lf x, int lane)
 }
 DCP_FN uint32_t read_laneu(lu x, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)x, lane); }
 
+// ---- the group of lanes that shares one DP problem ------------------------------
+// W = 1: one wavefront; every exchange is DPP / readlane and the put_*/sync
+// calls vanish.  W > 1: a workgroup of W wavefronts (K > 256); values that cross
+// a wave boundary go through a few LDS words, published by put_*(), made
+// visible by sync() (s_barrier) and consumed by the matching get_*().  A slot is
+// never re-published before every wave has passed a later sync(), so one buffer
+// per slot is enough.
+enum { GS_M, GS_I, GS_D, GS_E, GS_F, GS_X, GS_T0, GS_T1, GS_SLOTS };
+
+template <int W> struct Group;
+
+template <> struct Group<1>
+{
+  lu lane; // 0..63
+  DCP_FN void init() { lane = lane_ids(); }
+  DCP_FN void put_last(int, lf) {}
+  DCP_FN void put_min(int, lf) {}
+  DCP_FN void put_minu(int, lu) {}
+  DCP_FN void put_lanes4(int, lf) {}
+  DCP_FN void put_any(int, lm) {}
+  DCP_FN void put_count(int, lm) {}
+  DCP_FN void sync() {}
+  DCP_FN lf get_shift(int, lf x, float fill) { return lane_shift_up(x, fill); }
+  DCP_FN float get_min(int, lf x) { return wave_min(x); }
+  DCP_FN uint32_t get_minu(int, lu x) { return wave_minu(x); }
+  DCP_FN float get_lane(int, lf x, int l) { return read_lane(x, l); }
+  DCP_FN bool get_any(int, lm m) { return wave_any(m); }
+  DCP_FN int get_count(int, lm m) { return __builtin_popcountll(wave_ballot(m)); }
+};
+
+template <int W> struct Group
+{
+  lu lane;        // 0..64*W-1, position of this lane in the group
+  int wave;       // wave index inside the workgroup (uniform)
+  float *lds;     // [GS_SLOTS][16] words
+  DCP_FN void init()
+  {
+    static_assert(W <= 16, "a workgroup holds at most 16 wavefronts");
+    __shared__ float scratch[GS_SLOTS * 16];
+    lds = scratch;
+    wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    lane = lane_ids() + (uint32_t)wave * 64u;
+  }
+  DCP_FN bool last_lane() const { return (lane & 63u) == 63u; }
+  DCP_FN void put_last(int slot, lf x)
+  {
+    if (last_lane()) lds[slot * 16 + wave] = x;
+  }
+  DCP_FN void put_min(int slot, lf x)
+  {
+    float const m = wave_min(x);
+    if (last_lane()) lds[slot * 16 + wave] = m;
+  }
+  DCP_FN void put_minu(int slot, lu x)
+  {
+    uint32_t const m = wave_minu(x);
+    if (last_lane()) lds[slot * 16 + wave] = __uint_as_float(m);
+  }
+  DCP_FN void put_lanes4(int slot, lf x) // lanes 0..3 of wave 0 hold the special states
+  {
+    if (lane < 4u) lds[slot * 16 + lane] = x;
+  }
+  DCP_FN void put_any(int slot, lm m)
+  {
+    bool const a = wave_any(m);
+    if (last_lane()) lds[slot * 16 + wave] = a ? 1.0f : 0.0f;
+  }
+  DCP_FN void put_count(int slot, lm m)
+  {
+    int const c = __builtin_popcountll(wave_ballot(m));
+    if (last_lane()) lds[slot * 16 + wave] = (float)c;
+  }
+  DCP_FN void sync() { __syncthreads(); }
+  DCP_FN lf get_shift(int slot, lf x, float fill)
+  {
+    float const prev = wave > 0 ? lds[slot * 16 + wave - 1] : fill;
+    return lane_shift_up(x, prev);
+  }
+  DCP_FN float get_min(int slot, lf)
+  {
+    float m = lds[slot * 16];
+#pragma unroll
+    for (int w = 1; w < W; ++w) m = __builtin_fminf(m, lds[slot * 16 + w]);
+    return m;
+  }
+  DCP_FN uint32_t get_minu(int slot, lu)
+  {
+    uint32_t m = __float_as_uint(lds[slot * 16]);
+#pragma unroll
+    for (int w = 1; w < W; ++w)
+    {
+      uint32_t const v = __float_as_uint(lds[slot * 16 + w]);
+      m = v < m ? v : m;
+    }
+    return m;
+  }
+  DCP_FN float get_lane(int slot, lf, int l) { return lds[slot * 16 + l]; }
+  DCP_FN bool get_any(int slot, lm)
+  {
+    float a = 0.0f;
+#pragma unroll
+    for (int w = 0; w < W; ++w) a += lds[slot * 16 + w];
+    return a != 0.0f;
+  }
+  DCP_FN int get_count(int slot, lm)
+  {
+    float a = 0.0f;
+#pragma unroll
+    for (int w = 0; w < W; ++w) a += lds[slot * 16 + w];
+    return (int)a;
+  }
+};
+
 // ---- memory -------------------------------------------------------------------
 // Each lane owns Q consecutive profile positions k = lane*Q + q; a padded row of
 // Kp = 64*Q floats is therefore read as one coalesced dword x Q load per lane.

@@ -48,8 +48,9 @@ DCP_FN void dcp_unpack_codes(uint4 cr, unsigned (&c)[5])
 // some M_l[j] plus non-negative delete costs (costs are -log-probabilities), so
 // they never lower the minimum.
 // =============================================================================
-template <int Q> struct CostWave
+template <int Q, int W> struct CostWave
 {
+  Group<W> g;
   lf BM[Q], MM[Q], MI[Q], MD[Q], IM[Q], II[Q], DM[Q], DD[Q];
   lf Mpre[5][Q], Ipre[5][Q], Spre[5];
   lf em[5][Q];
@@ -58,7 +59,6 @@ template <int Q> struct CostWave
   float nil[5], bgv[5];
   float NB, EB, JB, ET, CT, RR;
   float E;
-  lu lane;
   float const *__restrict__ match;
   float const *__restrict__ nullc;
   float const *__restrict__ bgc;
@@ -74,14 +74,15 @@ template <int Q> struct CostWave
     {
       nil[t] = nullc[c[t]];
       bgv[t] = bgc[c[t]];
-      load_q<Q>(match + (size_t)c[t] * (size_t)Kp, lane, em[t]);
+      load_q<Q>(match + (size_t)c[t] * (size_t)Kp, g.lane, em[t]);
     }
   }
 
   DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, uint4 const *__restrict__ code_rows,
                    float const *__restrict__ xt)
   {
-    lane = lane_ids();
+    g.init();
+    lu const lane = g.lane;
     match = pool + pf.match_off;
     nullc = pool + pf.null_off;
     bgc = pool + pf.bg_off;
@@ -148,33 +149,45 @@ template <int Q> struct CostWave
     // emissions of this row are consumed: fetch the next row's behind the rest
     if (l < L) prefetch(l + 1);
 
-    // D_l[k] = min(M_l[k-1] + MD[k], D_l[k-1] + DD[k])  (c-core/viterbi.c:538,553-580)
-    lf const Msh0 = lane_shift_up(M[Q - 1], DCP_INF);
-    D[0] = Msh0 + MD[0];
-#pragma unroll
-    for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
-    // carries across lanes, repeated until no lane improves (the reference's
-    // lazy D->D loop, c-core/viterbi.c:569-580)
-    lf x = lane_shift_up(D[Q - 1], DCP_INF) + DD[0];
-    while (wave_any(llt(x, D[0])))
-    {
-      D[0] = lmin(D[0], x);
-#pragma unroll
-      for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
-      x = lane_shift_up(D[Q - 1], DCP_INF) + DD[0];
-    }
-
     lf m = M[0];
 #pragma unroll
     for (int q = 1; q < Q; ++q) m = lmin(m, M[q]);
-    E = wave_min(m);
-    float const N = read_lane(X, 0);
-    float const J = read_lane(X, 1);
+    // what crosses a wave boundary (nothing to publish when the group is one wave)
+    g.put_last(GS_M, M[Q - 1]);
+    g.put_last(GS_I, I[Q - 1]);
+    g.put_min(GS_E, m);
+    g.put_lanes4(GS_X, X);
+    g.sync();
+    lf const Msh0 = g.get_shift(GS_M, M[Q - 1], DCP_INF);
+    lf const Ish0 = g.get_shift(GS_I, I[Q - 1], DCP_INF);
+    E = g.get_min(GS_E, m);
+    float const N = g.get_lane(GS_X, X, 0);
+    float const J = g.get_lane(GS_X, X, 1);
     float const B = __builtin_fminf(__builtin_fminf(N + NB, E + EB), J + JB); // c-core/viterbi.c:495-496,582-583
 
+    // D_l[k] = min(M_l[k-1] + MD[k], D_l[k-1] + DD[k])  (c-core/viterbi.c:538,553-580):
+    // serial inside a lane, then carried across lanes until no lane improves (the
+    // reference's lazy D->D loop, c-core/viterbi.c:569-580)
+    D[0] = Msh0 + MD[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
+    lf Dsh0;
+    for (;;)
+    {
+      g.put_last(GS_D, D[Q - 1]);
+      g.sync();
+      Dsh0 = g.get_shift(GS_D, D[Q - 1], DCP_INF);
+      lf const x = Dsh0 + DD[0];
+      lm const better = llt(x, D[0]);
+      g.put_any(GS_F, better);
+      g.sync();
+      if (!g.get_any(GS_F, better)) break;
+      D[0] = lmin(D[0], x);
+#pragma unroll
+      for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+    }
+
     // fold row l into the ring (slot P held row l-5, no longer needed)
-    lf const Ish0 = lane_shift_up(I[Q - 1], DCP_INF);
-    lf const Dsh0 = lane_shift_up(D[Q - 1], DCP_INF);
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {
@@ -204,11 +217,14 @@ template <int Q> struct CostWave
     if (l <= L) row<2>(l++, L);
     if (l <= L) row<3>(l++, L);
     if (l <= L) row<4>(l++, L);
-    float const C = read_lane(X, 2);
-    float const R = read_lane(X, 3);
+    g.sync();
+    g.put_lanes4(GS_X, X);
+    g.sync();
+    float const C = g.get_lane(GS_X, X, 2);
+    float const R = g.get_lane(GS_X, X, 3);
     float const T = L > 0 ? __builtin_fminf(E + ET, C + CT) : DCP_INF; // c-core/viterbi.c:585-586,599
-    store_f32_lane0(out + 0, lane, R);
-    store_f32_lane0(out + 1, lane, T);
+    store_f32_lane0(out + 0, g.lane, R);
+    store_f32_lane0(out + 1, g.lane, T);
   }
 };
 
@@ -235,14 +251,14 @@ template <int Q> struct CostWave
     (cur) = __builtin_fminf((cur), v_);                                        \
   } while (0)
 
-template <int Q> struct PathWave
+template <int Q, int W> struct PathWave
 {
+  Group<W> g;
   lf BM[Q], MM[Q], MI[Q], MD[Q], IM[Q], II[Q], DM[Q], DD[Q];
   // ring of the five previous rows; *sh = value of position k-1 for q = 0
   lf M[5][Q], I[5][Q], D[5][Q], Msh[5], Ish[5], Dsh[5];
   float S[5], N[5], B[5], J[5], E[5], C[5];
   float xt[DCP_NUM_XTRANS];
-  lu lane;
   int K, Kp;
   float const *__restrict__ match;
   float const *__restrict__ nullc;
@@ -254,7 +270,8 @@ template <int Q> struct PathWave
   DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, uint4 const *__restrict__ code_rows,
                    float const *__restrict__ xtp, uint32_t *__restrict__ xn, uint16_t *__restrict__ nd)
   {
-    lane = lane_ids();
+    g.init();
+    lu const lane = g.lane;
     K = pf.K;
     Kp = pf.Kp;
     match = pool + pf.match_off;
@@ -302,25 +319,36 @@ template <int Q> struct PathWave
                           lf const (&Dbefore)[Q])
   {
     if (!(v < DCP_INF)) return 0u;
+    lu const lane = g.lane;
     lf const vv = lf_splat(v);
-    int total = 0;
     lu field = lu_splat(0xffffffffu);
+    lm has = llt_u(lu_splat(1), lu_splat(0)); // all false
+    lm multi = has;
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {
       lu const k2 = (lane * (uint32_t)Q + (uint32_t)q) * 2u;
       lm const mM = leq(Ma[q], vv), mD = leq(Da[q], vv);
-      total += __builtin_popcountll(wave_ballot(mM)) + __builtin_popcountll(wave_ballot(mD));
+      multi = lor(multi, lor(land(has, lor(mM, mD)), land(mM, mD)));
+      has = lor(has, lor(mM, mD));
       field = lselu(mD, lminu(field, k2 + 1u), field);
       field = lselu(mM, lminu(field, k2), field);
     }
-    if (total == 1) return wave_minu(field);
+    g.put_count(GS_F, has);
+    g.put_any(GS_X, multi);
+    g.put_minu(GS_T0, field);
+    g.sync();
+    bool const single = g.get_count(GS_F, has) == 1 && !g.get_any(GS_X, multi);
+    uint32_t const first = g.get_minu(GS_T0, field);
+    if (single) return first;
 
     // exact tie between distinct candidates: apply the reference's rule
     int Qr = (K - 1) / DCP_REF_LANES + 1;
     if (Qr < 2) Qr = 2; // c-core/viterbi.c:195-199
     lf stale[Q];
-    lf const Mb0 = lane_shift_up(Mbefore[Q - 1], DCP_INF);
+    g.put_last(GS_M, Mbefore[Q - 1]);
+    g.sync();
+    lf const Mb0 = g.get_shift(GS_M, Mbefore[Q - 1], DCP_INF);
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {
@@ -344,7 +372,10 @@ template <int Q> struct PathWave
         ord = lselu(land(in, leq(Ma[q], vv)), lminu(ord, ordM), ord);
         ord = lselu(land(in, leq(Da[q], vv)), lminu(ord, ordD), ord);
       }
-      uint32_t const w = wave_minu(ord);
+      int const slot = (er & 1) ? GS_T1 : GS_T0; // alternate: a slot is re-published only after a later sync
+      g.put_minu(slot, ord);
+      g.sync();
+      uint32_t const w = g.get_minu(slot, ord);
       if (w != 0xffffffffu)
       {
         uint32_t name, qr;
@@ -370,7 +401,7 @@ template <int Q> struct PathWave
     float const nil = nullc[code];
     float const bg = bgc[code];
     lf em[Q];
-    load_q<Q>(match + (size_t)code * (size_t)Kp, lane, em);
+    load_q<Q>(match + (size_t)code * (size_t)Kp, g.lane, em);
 
     DCP_UPDS(Na, pN, (S[Z] + xt[DCP_SN]) + nil, 0u + u); // c-core/viterbi.c:492-493
     DCP_UPDS(Na, pN, (N[Z] + xt[DCP_NN]) + nil, 5u + u);
@@ -402,7 +433,9 @@ template <int Q> struct PathWave
       DCP_UPD(Ia[q], pI[q], (I[Z][q] + II[q]) + lf_splat(bg), 5u + u);
       DCP_UPD(Ia[q], pI[q], (M[Z][q] + MI[q]) + lf_splat(bg), 0u + u);
     }
-    lf const Mash0 = lane_shift_up(Ma[Q - 1], DCP_INF);
+    g.put_last(GS_M, Ma[Q - 1]);
+    g.sync();
+    lf const Mash0 = g.get_shift(GS_M, Ma[Q - 1], DCP_INF);
 #pragma unroll
     for (int q = 0; q < Q; ++q) // :538 and the stripe-0 repair :553-555
     {
@@ -413,20 +446,27 @@ template <int Q> struct PathWave
     lf m = lmin(Ma[0], Da[0]); // :540-541,556-558
 #pragma unroll
     for (int q = 1; q < Q; ++q) m = lmin(m, lmin(Ma[q], Da[q]));
-    Ea = wave_min(m);
+    g.put_min(GS_E, m);
+    g.sync();
+    Ea = g.get_min(GS_E, m);
     if (T == 1) pE = e_field(Ea, Ma, Da, Mbefore, Dbefore);
 
     // D -> D: serial in k; done per lane, then carried across lanes until nothing
     // improves (:561-580).  Strict-< updates make the pointers order-free.
 #pragma unroll
     for (int q = 1; q < Q; ++q) DCP_UPD(Da[q], pD[q], Da[q - 1] + DD[q], 1u);
-    lf x = lane_shift_up(Da[Q - 1], DCP_INF) + DD[0];
-    while (wave_any(llt(x, Da[0])))
+    for (;;)
     {
+      g.put_last(GS_D, Da[Q - 1]);
+      g.sync();
+      lf const x = g.get_shift(GS_D, Da[Q - 1], DCP_INF) + DD[0];
+      lm const better = llt(x, Da[0]);
+      g.put_any(GS_F, better);
+      g.sync();
+      if (!g.get_any(GS_F, better)) break;
       DCP_UPD(Da[0], pD[0], x, 1u);
 #pragma unroll
       for (int q = 1; q < Q; ++q) DCP_UPD(Da[q], pD[q], Da[q - 1] + DD[q], 1u);
-      x = lane_shift_up(Da[Q - 1], DCP_INF) + DD[0];
     }
 
     DCP_UPDS(Ba, pB, Ea + xt[DCP_EB], 2u); // :582-583
@@ -458,6 +498,7 @@ template <int Q> struct PathWave
     pass<1, DCP_SL(P, 1)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[0]);
 
     // after(): pack the row's pointers (c-core/viterbi.c:631-694)
+    lu const lane = g.lane;
     store_u32_lane0(xnodes + l, lane, (pN << 0) | (pB << 4) | (pE << 6) | (pC << 21) | (pT << 25) | (pJ << 26));
     lu w[Q];
 #pragma unroll
@@ -479,9 +520,13 @@ template <int Q> struct PathWave
       I[P][q] = Ia[q];
       D[P][q] = Da[q];
     }
-    Msh[P] = lane_shift_up(Ma[Q - 1], DCP_INF);
-    Ish[P] = lane_shift_up(Ia[Q - 1], DCP_INF);
-    Dsh[P] = lane_shift_up(Da[Q - 1], DCP_INF);
+    g.put_last(GS_M, Ma[Q - 1]);
+    g.put_last(GS_I, Ia[Q - 1]);
+    g.put_last(GS_D, Da[Q - 1]);
+    g.sync();
+    Msh[P] = g.get_shift(GS_M, Ma[Q - 1], DCP_INF);
+    Ish[P] = g.get_shift(GS_I, Ia[Q - 1], DCP_INF);
+    Dsh[P] = g.get_shift(GS_D, Da[Q - 1], DCP_INF);
     S[P] = DCP_INF;
     N[P] = Na;
     B[P] = Ba;

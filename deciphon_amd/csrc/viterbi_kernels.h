@@ -3,13 +3,18 @@
 #include "dcp_types.h"
 #include <hip/hip_runtime.h>
 
-#define DCP_MAX_Q 4 // single-wave kernels cover K <= 64 * DCP_MAX_Q
+// kernel classes (Q positions per lane, W wavefronts per problem):
+//   0..3: (1..4, 1) K <= 64..256;  4..7: (4, 2/4/8/16) K <= 512/1024/2048/4096
+#define DCP_NUM_CLASSES 8
+#define DCP_MAX_CORE_SIZE 4096
+int dcp_class_of(int K);                      // -1 when K is not covered
+void dcp_class_shape(int cls, int *Q, int *W);
 
 struct DcpLaunch
 {
   float const *pool;             // device: all profile arrays
   DcpProfileDev const *profiles; // device
-  DcpProblem const *problems;    // device, all with the same Q
+  DcpProblem const *problems;    // device, all of one kernel class
   DcpCodeRow const *code_rows;   // device
   float const *xt_table;         // device, [rows][DCP_XT_STRIDE]
   float *out;                    // device: cost pass [2*slots] (null, alt); path pass [slots]
@@ -18,7 +23,7 @@ struct DcpLaunch
   hipStream_t stream;
 };
 
-hipError_t dcp_launch_cost(int Q, DcpLaunch const &a);
-hipError_t dcp_launch_path(int Q, DcpLaunch const &a);
+hipError_t dcp_launch_cost(int cls, DcpLaunch const &a);
+hipError_t dcp_launch_path(int cls, DcpLaunch const &a);
 hipError_t dcp_launch_encode(unsigned char const *nt, int64_t const *seq_off, int64_t const *row_off, int nseq,
                              int64_t max_len, DcpCodeRow *rows, hipStream_t stream);

@@ -1,13 +1,14 @@
 // viterbi_kernels.hip -- gfx950 kernels of the Viterbi scan path.
 //
-// One wavefront (= one 64-thread workgroup) per (profile x window) problem.
-// Problems of one launch share the positions-per-lane count Q (K <= 64*Q).
+// One workgroup per (profile x window) problem: a single wavefront for K <= 256
+// (Q = 1..4 positions per lane), W = 2..16 wavefronts of Q = 4 beyond that.
+// Problems of one launch share the kernel class (Q, W), K <= 64*Q*W.
 #include "lane_ops_gpu.h"
 #include "viterbi_body.h"
 #include "viterbi_kernels.h"
 
-template <int Q>
-__global__ __launch_bounds__(64) void dcp_cost_kernel(float const *__restrict__ pool,
+template <int Q, int W>
+__global__ __launch_bounds__(64 * W) void dcp_cost_kernel(float const *__restrict__ pool,
                                                       DcpProfileDev const *__restrict__ profiles,
                                                       DcpProblem const *__restrict__ problems,
                                                       uint4 const *__restrict__ code_rows,
@@ -18,13 +19,13 @@ __global__ __launch_bounds__(64) void dcp_cost_kernel(float const *__restrict__ 
   if (p >= nprob) return;
   DcpProblem const pb = problems[p];
   DcpProfileDev const pf = profiles[pb.profile];
-  CostWave<Q> w;
+  CostWave<Q, W> w;
   w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
   w.run(pb.L, out + 2 * (size_t)pb.out);
 }
 
-template <int Q>
-__global__ __launch_bounds__(64) void dcp_path_kernel(float const *__restrict__ pool,
+template <int Q, int W>
+__global__ __launch_bounds__(64 * W) void dcp_path_kernel(float const *__restrict__ pool,
                                                       DcpProfileDev const *__restrict__ profiles,
                                                       DcpProblem const *__restrict__ problems,
                                                       uint4 const *__restrict__ code_rows,
@@ -39,10 +40,10 @@ __global__ __launch_bounds__(64) void dcp_path_kernel(float const *__restrict__ 
   // trellis of a problem: uint32 xnodes[L+1] then uint16 nodes[(L+1)*K]
   uint32_t *xnodes = reinterpret_cast<uint32_t *>(arena + pb.trellis);
   uint16_t *nodes = reinterpret_cast<uint16_t *>(xnodes + (pb.L + 1));
-  PathWave<Q> w;
+  PathWave<Q, W> w;
   w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE, xnodes, nodes);
   float const T = w.run(pb.L);
-  store_f32_lane0(out + pb.out, w.lane, T);
+  store_f32_lane0(out + pb.out, w.g.lane, T);
 }
 
 // Code rows of one encoded sequence: row r (1..n) holds the codes of the
@@ -75,42 +76,69 @@ __global__ void dcp_encode_kernel(unsigned char const *__restrict__ nt, int64_t 
   }
 }
 
-template <int Q> static hipError_t launch_cost_q(DcpLaunch const &a)
+template <int Q, int W> static hipError_t launch_cost_qw(DcpLaunch const &a)
 {
-  hipLaunchKernelGGL(dcp_cost_kernel<Q>, dim3((unsigned)a.nprob), dim3(64), 0, a.stream, a.pool, a.profiles, a.problems,
-                     reinterpret_cast<uint4 const *>(a.code_rows), a.xt_table, a.out, a.nprob);
+  hipLaunchKernelGGL((dcp_cost_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool, a.profiles,
+                     a.problems, reinterpret_cast<uint4 const *>(a.code_rows), a.xt_table, a.out, a.nprob);
   return hipGetLastError();
 }
 
-template <int Q> static hipError_t launch_path_q(DcpLaunch const &a)
+template <int Q, int W> static hipError_t launch_path_qw(DcpLaunch const &a)
 {
-  hipLaunchKernelGGL(dcp_path_kernel<Q>, dim3((unsigned)a.nprob), dim3(64), 0, a.stream, a.pool, a.profiles, a.problems,
-                     reinterpret_cast<uint4 const *>(a.code_rows), a.xt_table, a.arena, a.out, a.nprob);
+  hipLaunchKernelGGL((dcp_path_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool, a.profiles,
+                     a.problems, reinterpret_cast<uint4 const *>(a.code_rows), a.xt_table, a.arena, a.out, a.nprob);
   return hipGetLastError();
 }
 
-hipError_t dcp_launch_cost(int Q, DcpLaunch const &a)
+int dcp_class_of(int K)
+{
+  if (K < 1) return -1;
+  if (K <= 256) return (K + 63) / 64 - 1; // classes 0..3: one wave, Q = 1..4
+  if (K <= 512) return 4;
+  if (K <= 1024) return 5;
+  if (K <= 2048) return 6;
+  if (K <= 4096) return 7;
+  return -1;
+}
+
+void dcp_class_shape(int cls, int *Q, int *W)
+{
+  static int const q[DCP_NUM_CLASSES] = {1, 2, 3, 4, 4, 4, 4, 4};
+  static int const w[DCP_NUM_CLASSES] = {1, 1, 1, 1, 2, 4, 8, 16};
+  *Q = q[cls];
+  *W = w[cls];
+}
+
+hipError_t dcp_launch_cost(int cls, DcpLaunch const &a)
 {
   if (a.nprob <= 0) return hipSuccess;
-  switch (Q)
+  switch (cls)
   {
-  case 1: return launch_cost_q<1>(a);
-  case 2: return launch_cost_q<2>(a);
-  case 3: return launch_cost_q<3>(a);
-  case 4: return launch_cost_q<4>(a);
+  case 0: return launch_cost_qw<1, 1>(a);
+  case 1: return launch_cost_qw<2, 1>(a);
+  case 2: return launch_cost_qw<3, 1>(a);
+  case 3: return launch_cost_qw<4, 1>(a);
+  case 4: return launch_cost_qw<4, 2>(a);
+  case 5: return launch_cost_qw<4, 4>(a);
+  case 6: return launch_cost_qw<4, 8>(a);
+  case 7: return launch_cost_qw<4, 16>(a);
   default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t dcp_launch_path(int Q, DcpLaunch const &a)
+hipError_t dcp_launch_path(int cls, DcpLaunch const &a)
 {
   if (a.nprob <= 0) return hipSuccess;
-  switch (Q)
+  switch (cls)
   {
-  case 1: return launch_path_q<1>(a);
-  case 2: return launch_path_q<2>(a);
-  case 3: return launch_path_q<3>(a);
-  case 4: return launch_path_q<4>(a);
+  case 0: return launch_path_qw<1, 1>(a);
+  case 1: return launch_path_qw<2, 1>(a);
+  case 2: return launch_path_qw<3, 1>(a);
+  case 3: return launch_path_qw<4, 1>(a);
+  case 4: return launch_path_qw<4, 2>(a);
+  case 5: return launch_path_qw<4, 4>(a);
+  case 6: return launch_path_qw<4, 8>(a);
+  case 7: return launch_path_qw<4, 16>(a);
   default: return hipErrorInvalidValue;
   }
 }

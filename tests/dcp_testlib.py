@@ -52,22 +52,30 @@ def synth_profile(rng, K: int, quant=None, pinf: float = 0.0) -> Profile:
     return Profile(K, np.ascontiguousarray(trans), np.ascontiguousarray(match), null, bg, f"SYN{K}")
 
 
-def choose_q(K: int) -> int:
-    return max(1, (K + 63) // 64)
+def choose_qw(K: int):
+    """(positions per lane, waves per problem): one wave up to K = 256, then 4 positions
+    per lane and 2/4/8/16 waves (deciphon_amd/csrc/engine.cpp: choose_class)."""
+    if K <= 256:
+        return max(1, (K + 63) // 64), 1
+    for W in (2, 4, 8, 16):
+        if K <= 256 * W:
+            return 4, W
+    raise ValueError("core size beyond 4096")
 
 
-def pack_profile(prof: Profile, Q: int | None = None):
+def pack_profile(prof: Profile, Q: int | None = None, W: int | None = None):
     """-> (pool float32[...], ProfileDev) in the padded layout the kernels read."""
     K = prof.K
-    Q = Q or choose_q(K)
-    Kp = 64 * Q
+    if Q is None or W is None:
+        Q, W = choose_qw(K)
+    Kp = 64 * Q * W
     assert K <= Kp
     match = np.full((TABLE_SIZE, Kp), INF, dtype=np.float32)
     match[:, :K] = prof.match
     trans = np.full((8, Kp), INF, dtype=np.float32)
     trans[:, :K] = prof.trans
     pool = np.concatenate([match.ravel(), trans.ravel(), prof.null, prof.bg]).astype(np.float32)
-    pd = ProfileDev(K, Kp, Q, 1, 0, match.size, match.size + trans.size, match.size + trans.size + TABLE_SIZE)
+    pd = ProfileDev(K, Kp, Q, W, 0, match.size, match.size + trans.size, match.size + trans.size + TABLE_SIZE)
     return pool, pd
 
 

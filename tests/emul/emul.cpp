@@ -4,19 +4,19 @@
 #include "lane_ops_emul.h"
 #include "../../deciphon_amd/csrc/viterbi_body.h"
 
-template <int Q>
+template <int Q, int W>
 static void cost_q(float const *pool, DcpProfileDev const &pf, uint4 const *codes, int L, float const *xt, float *out)
 {
-  CostWave<Q> w;
+  static thread_local CostWave<Q, W> w; // 64*W-lane vectors are large: keep them off the stack
   w.init(pool, pf, codes, xt);
   w.run(L, out);
 }
 
-template <int Q>
+template <int Q, int W>
 static float path_q(float const *pool, DcpProfileDev const &pf, uint4 const *codes, int L, float const *xt,
                     uint32_t *xnodes, uint16_t *nodes)
 {
-  PathWave<Q> w;
+  static thread_local PathWave<Q, W> w;
   w.init(pool, pf, codes, xt, xnodes, nodes);
   return w.run(L);
 }
@@ -25,12 +25,16 @@ extern "C" int emul_cost(float const *pool, DcpProfileDev const *pf, DcpCodeRow 
                          float *out)
 {
   uint4 const *c = reinterpret_cast<uint4 const *>(codes);
-  switch (pf->Q)
+  switch (pf->Q * 100 + pf->W)
   {
-  case 1: cost_q<1>(pool, *pf, c, L, xt, out); return 0;
-  case 2: cost_q<2>(pool, *pf, c, L, xt, out); return 0;
-  case 3: cost_q<3>(pool, *pf, c, L, xt, out); return 0;
-  case 4: cost_q<4>(pool, *pf, c, L, xt, out); return 0;
+  case 101: cost_q<1, 1>(pool, *pf, c, L, xt, out); return 0;
+  case 201: cost_q<2, 1>(pool, *pf, c, L, xt, out); return 0;
+  case 301: cost_q<3, 1>(pool, *pf, c, L, xt, out); return 0;
+  case 401: cost_q<4, 1>(pool, *pf, c, L, xt, out); return 0;
+  case 402: cost_q<4, 2>(pool, *pf, c, L, xt, out); return 0;
+  case 404: cost_q<4, 4>(pool, *pf, c, L, xt, out); return 0;
+  case 408: cost_q<4, 8>(pool, *pf, c, L, xt, out); return 0;
+  case 416: cost_q<4, 16>(pool, *pf, c, L, xt, out); return 0;
   default: return -1;
   }
 }
@@ -39,12 +43,16 @@ extern "C" int emul_path(float const *pool, DcpProfileDev const *pf, DcpCodeRow 
                          uint32_t *xnodes, uint16_t *nodes, float *score)
 {
   uint4 const *c = reinterpret_cast<uint4 const *>(codes);
-  switch (pf->Q)
+  switch (pf->Q * 100 + pf->W)
   {
-  case 1: *score = path_q<1>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
-  case 2: *score = path_q<2>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
-  case 3: *score = path_q<3>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
-  case 4: *score = path_q<4>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 101: *score = path_q<1, 1>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 201: *score = path_q<2, 1>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 301: *score = path_q<3, 1>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 401: *score = path_q<4, 1>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 402: *score = path_q<4, 2>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 404: *score = path_q<4, 4>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 408: *score = path_q<4, 8>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 416: *score = path_q<4, 16>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
   default: return -1;
   }
 }

@@ -13,11 +13,16 @@
 
 struct uint4 { uint32_t x, y, z, w; };
 
-struct lf { float v[64]; };
-struct lu { uint32_t v[64]; };
-struct lm { bool v[64]; };
+// A "group" of W wavefronts is emulated as ONE vector of 64*W lanes: values that the GPU
+// moves across wave boundaries through LDS simply shift / reduce across the whole vector.
+#define EM_MAX_LANES 1024
+static thread_local int em_lanes = 64;
 
-#define EM_FOR for (int i_ = 0; i_ < 64; ++i_)
+struct lf { float v[EM_MAX_LANES]; };
+struct lu { uint32_t v[EM_MAX_LANES]; };
+struct lm { bool v[EM_MAX_LANES]; };
+
+#define EM_FOR for (int i_ = 0; i_ < em_lanes; ++i_)
 
 inline lf lf_splat(float x) { lf r; EM_FOR r.v[i_] = x; return r; }
 inline lu lu_splat(uint32_t x) { lu r; EM_FOR r.v[i_] = x; return r; }
@@ -50,7 +55,7 @@ inline lf lane_shift_up(lf x, float fill)
 {
   lf r;
   r.v[0] = fill;
-  for (int i = 1; i < 64; ++i) r.v[i] = x.v[i - 1];
+  for (int i = 1; i < em_lanes; ++i) r.v[i] = x.v[i - 1];
   return r;
 }
 
@@ -60,6 +65,31 @@ inline bool wave_any(lm m) { EM_FOR if (m.v[i_]) return true; return false; }
 inline uint64_t wave_ballot(lm m) { uint64_t b = 0; EM_FOR if (m.v[i_]) b |= 1ull << i_; return b; }
 inline float read_lane(lf x, int lane) { return x.v[lane]; }
 inline uint32_t read_laneu(lu x, int lane) { return x.v[lane]; }
+
+enum { GS_M, GS_I, GS_D, GS_E, GS_F, GS_X, GS_T0, GS_T1, GS_SLOTS };
+
+template <int W> struct Group
+{
+  lu lane;
+  void init()
+  {
+    em_lanes = 64 * W;
+    lane = lane_ids();
+  }
+  void put_last(int, lf) {}
+  void put_min(int, lf) {}
+  void put_minu(int, lu) {}
+  void put_lanes4(int, lf) {}
+  void put_any(int, lm) {}
+  void put_count(int, lm) {}
+  void sync() {}
+  lf get_shift(int, lf x, float fill) { return lane_shift_up(x, fill); }
+  float get_min(int, lf x) { return wave_min(x); }
+  uint32_t get_minu(int, lu x) { return wave_minu(x); }
+  float get_lane(int, lf x, int l) { return read_lane(x, l); }
+  bool get_any(int, lm m) { return wave_any(m); }
+  int get_count(int, lm m) { int c = 0; EM_FOR c += m.v[i_] ? 1 : 0; return c; }
+};
 
 template <int Q> inline void load_q(float const *row, lu lane, lf (&out)[Q])
 {

@@ -94,6 +94,30 @@ def test_long_delete_runs_cross_many_lanes(em, orc):
         assert ((no >> 5) & 1).sum() > K  # plenty of D<-D pointers were taken
 
 
+def test_long_profiles_as_multi_wave_groups(em, orc):
+    """K > 256: W = 2..16 wavefronts per problem, emulated as one 64*W-lane vector.  Checks the
+    group-level logic (what is exchanged, in which order); the LDS/barrier lowering is GPU-only."""
+    rng = np.random.default_rng(17)
+    for it in range(40):
+        K = int(rng.choice([257, 300, 511, 512, 513, 700, 1024, 1025, 1500, 2048, 2049, 3000, 4096]))
+        quant = [None, 1.0, 4.0][it % 3]
+        prof = synth_profile(rng, K, quant, [0, 0.05][it % 2])
+        if it % 5 == 0:  # long delete runs that cross wave boundaries
+            prof.trans[7, 1:] = np.float32(0.01)
+            prof.trans[3, 1:] = np.float32(0.02)
+            prof.trans[1, 1:] = np.float32(9.0)
+            prof.match[:, K // 3:] += np.float32(30.0)
+        seq = random_seq(rng, int(rng.integers(1, 12)))
+        xt = orc.xtrans(max(len(seq) // 3, 1), it % 2, 0)
+        if quant:
+            xt = (np.round(xt / quant) * quant).astype(np.float32)
+        out = run_cost(em, prof, xt, seq)
+        assert bits(out[0]) == bits(orc.null(prof, xt, seq)) and bits(out[1]) == bits(orc.cost(prof, xt, seq)), (it, K)
+        score, xn, nd = run_path(em, prof, xt, seq)
+        s_o, xo, no = orc.path(prof, xt, seq)
+        assert bits(score) == bits(s_o) and np.array_equal(xn, xo) and np.array_equal(nd, no), (it, K)
+
+
 def test_minifam_consensus_pairs(em, orc):
     db = read_dcp(os.path.join(GOLDEN, "minifam.dcp"))
     reads = [orc.encode(s) for _, s in read_fasta(os.path.join(GOLDEN, "consensus.fna"))]

@@ -175,6 +175,45 @@ def test_windows_inside_reads_and_ragged_batch(engine, orc):
         assert np.array_equal(paths[i]["xnodes"], xo) and np.array_equal(paths[i]["nodes"], no), wins[i]
 
 
+def test_long_profiles_multi_wave_kernels(engine, orc):
+    """K = 257..4096 run as workgroups of 2..16 wavefronts that exchange boundary values
+    through LDS; includes delete runs crossing wave boundaries and exact ties."""
+    rng = np.random.default_rng(23)
+    profs, quants = [], []
+    for it, K in enumerate((257, 300, 511, 512, 513, 700, 1024, 1025, 1500, 2048, 2049, 3000, 4096, 260, 1030, 2100)):
+        quant = [None, 1.0, 4.0][it % 3]
+        p = synth_profile(rng, K, quant, [0, 0.05][it % 2])
+        if it % 4 == 0:
+            p.trans[7, 1:] = np.float32(0.01)
+            p.trans[3, 1:] = np.float32(0.02)
+            p.trans[1, 1:] = np.float32(9.0)
+            p.match[:, K // 3:] += np.float32(30.0)
+        profs.append(p)
+        quants.append(quant)
+    engine.clear_profiles()
+    for p in profs:
+        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    engine.commit()
+    reads = [random_seq(rng, n) for n in (1, 4, 5, 9, 33, 64)]
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    wins = [(pi, si, 0, len(r)) for pi in range(len(profs)) for si, r in enumerate(reads)]
+    nul, alt = engine.cost(wins)
+    paths = engine.path(wins)
+    for i, (pi, si, a, b) in enumerate(wins):
+        seq = reads[si]
+        xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+        assert bits(nul[i]) == bits(orc.null(profs[pi], xt, seq)), wins[i]
+        assert bits(alt[i]) == bits(orc.cost(profs[pi], xt, seq)), (wins[i], profs[pi].K)
+        score, xo, no = orc.path(profs[pi], xt, seq)
+        assert bits(paths[i]["score"]) == bits(score), (wins[i], profs[pi].K)
+        assert np.array_equal(paths[i]["xnodes"], xo), (wins[i], profs[pi].K)
+        assert np.array_equal(paths[i]["nodes"], no), (wins[i], profs[pi].K)
+    with pytest.raises(Exception):
+        big = synth_profile(rng, 4097)
+        engine.add_profile(big.K, big.trans, big.match, big.null, big.bg)
+
+
 def test_empty_and_invalid_calls(engine):
     import deciphon_amd
 
