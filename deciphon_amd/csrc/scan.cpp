@@ -1,0 +1,406 @@
+// scan.cpp -- the reference's outer API (include/deciphon.h) on top of the engine.
+//
+// Replaces c-core/scan.c (orchestration), thread.c (thread_run / process_window),
+// workload.c / work.c (profile iteration), batch.c (reads) and the products.tsv
+// writer (product.c, product_thread.c), minus HMMER and codon decoding.
+//
+// The reference walks profile-major: for each profile, for each read, for each
+// window -- one DP at a time per thread.  Windows of ONE (profile, read) pair form
+// a chain (the next window starts after the previous window's hit,
+// c-core/window.c:21-31), but different pairs are independent, so the scan runs
+// in ROUNDS: round r scores window r of every pair that still has one, all in one
+// launch; the windows that pass the lrt filter go through the path pass together;
+// their hits set last_hit_pos and the pairs advance.  Rows are emitted in the
+// reference's order (profile, then read, then window) whatever the round order.
+#include "../../include/deciphon.h"
+#include "../../include/deciphon_hip.h"
+#include "dcp_db.h"
+#include "dcp_errors.h"
+#include "host_logic.h"
+
+#include <algorithm>
+#include <atomic>
+#include <errno.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+struct dcp_batch
+{
+  struct Seq
+  {
+    long id;
+    std::string name;
+    std::string text;        // uppercased + disambiguated (what dcp_batch_add stores, c-core/sequence.c:15-45)
+    std::vector<uint8_t> nt; // indices 0..3
+    bool has_t = false, has_u = false;
+  };
+  std::vector<Seq> seqs;
+};
+
+struct dcp_scan
+{
+  dcp_hip *eng = nullptr;
+  int device = 0;
+  bool multi_hits = true, hmmer3_compat = false;
+  void (*callback)(void *) = nullptr;
+  void *userdata = nullptr;
+  std::atomic<bool> interrupted{false};
+  std::atomic<int> done_proteins{0};
+  int num_proteins = 0;   // of this partition
+  int index_offset = 0;   // global index of local profile 0 (workload_index, c-core/workload.c:95)
+  std::string abc_name = "dna";
+  std::vector<std::string> products;
+};
+
+struct dcp_press
+{
+  int unused;
+};
+
+namespace
+{
+
+int loglevel() // c-core/loglevel.c:9-16
+{
+  static thread_local int level = 2;
+  static thread_local bool cached = false;
+  if (!cached)
+  {
+    char const *x = getenv("DECIPHON_LOGLEVEL");
+    if (x) level = atoi(x);
+    cached = true;
+  }
+  return level;
+}
+
+int raise(int rc, char const *func, char const *detail = nullptr) // c-core/error.c:103-121
+{
+  if (rc && loglevel() <= 2)
+    fprintf(stderr, "%s %s%s%s.\n", func, dcp_error_string(rc), detail ? ". Detail: " : "", detail ? detail : "");
+  return rc;
+}
+
+int mkdir_p(std::string const &dir)
+{
+  if (mkdir(dir.c_str(), 0755) == 0 || errno == EEXIST) return 0;
+  return DCP_EMKDIR;
+}
+
+struct Pair
+{
+  int profile, seq;
+  DcpWindow win;
+  bool active = true;
+  Pair(int p, int s, int seq_size, int core_size) : profile(p), seq(s), win(seq_size, core_size) {}
+};
+
+struct Row
+{
+  int profile, seq, window;
+  std::string text;
+};
+
+// product_thread_add_match (c-core/product_thread.c:40-79) without HMMER / decoder
+std::string format_row(dcp_batch::Seq const &seq, int window, int wstart, int wstop, DcpHit const &hit,
+                       char const *accession, char const *abc, float lrt, std::vector<int32_t> const &ids,
+                       std::vector<int32_t> const &sizes)
+{
+  char head[256];
+  snprintf(head, sizeof head, "%ld\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%s\t%.1f\tnan\t", seq.id, window, wstart, wstop, 0,
+           hit.hit_start, hit.hit_stop, accession, abc, (double)lrt);
+  std::string out = head;
+  int pos = 0;
+  for (int i = 0; i < hit.begin_step; ++i) pos += sizes[(size_t)i];
+  for (int i = hit.begin_step; i < hit.end_step; ++i)
+  {
+    if (i > hit.begin_step) out += ';';
+    char name[8];
+    dcp_state_name(ids[(size_t)i], name);
+    out.append(seq.text, (size_t)(wstart + pos), (size_t)sizes[(size_t)i]);
+    out += ',';
+    out += name;
+    out += ",,"; // codon and amino: c-core/decoder.c is out of scope
+    pos += sizes[(size_t)i];
+  }
+  return out;
+}
+
+int setup_common(dcp_scan *x, char const *dbfile, int device, int index, int nparts, bool multi_hits,
+                 bool hmmer3_compat, void (*callback)(void *), void *userdata)
+{
+  if (!x || !dbfile) return raise(DCP_EFUNCUSE, __func__);
+  if (nparts < 1) return raise(DCP_EZEROPART, __func__);
+  if (index < 0 || index >= nparts) return raise(DCP_EINVALPART, __func__);
+  DcpDbReader db;
+  int rc = db.open(dbfile);
+  if (rc) return raise(rc, __func__, dbfile);
+  int const abc = db.header().abc_typeid;
+  if (!(abc == 4 || abc == 5)) return raise(DCP_ENUCLTNOSUPPORT, __func__); // IMM_DNA / IMM_RNA
+  x->abc_name = abc == 4 ? "dna" : "rna";
+  int const N = db.num_proteins();
+  nparts = std::min(nparts, std::max(N, 1)); // c-core/scan.c:102
+  if (index >= nparts)
+  {
+    x->num_proteins = 0;
+    x->index_offset = N;
+  }
+  else
+  {
+    int first = 0;
+    for (int i = 0; i < index; ++i) first += (int)dcp_partition_size(N, nparts, i);
+    x->index_offset = first;
+    x->num_proteins = (int)dcp_partition_size(N, nparts, index);
+  }
+  if (x->eng) dcp_hip_del(x->eng);
+  x->eng = dcp_hip_new(device);
+  if (!x->eng) return raise(DCP_EFUNCUSE, __func__, "no usable HIP device (there is no CPU fallback)");
+  x->device = device;
+  if (x->num_proteins > 0)
+  {
+    if ((rc = dcp_hip_load_dcp(x->eng, dbfile, x->index_offset, x->num_proteins)))
+      return raise(rc, __func__, dcp_hip_strerror(x->eng));
+    if ((rc = dcp_hip_commit_profiles(x->eng))) return raise(rc, __func__, dcp_hip_strerror(x->eng));
+  }
+  if ((rc = dcp_hip_set_mode(x->eng, multi_hits, hmmer3_compat))) return raise(rc, __func__);
+  x->multi_hits = multi_hits;
+  x->hmmer3_compat = hmmer3_compat;
+  x->callback = callback;
+  x->userdata = userdata;
+  x->interrupted = false;
+  x->done_proteins = 0;
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+struct dcp_scan *dcp_scan_new(void) { return new (std::nothrow) dcp_scan; }
+
+void dcp_scan_del(struct dcp_scan const *cx)
+{
+  dcp_scan *x = const_cast<dcp_scan *>(cx);
+  if (!x) return;
+  if (x->eng) dcp_hip_del(x->eng);
+  delete x;
+}
+
+int dcp_scan_setup(struct dcp_scan *x, char const *dbfile, int port, int num_threads, bool multi_hits,
+                   bool hmmer3_compat, bool cache, void (*callback)(void *), void *userdata)
+{
+  (void)port;
+  (void)cache;
+  if (num_threads > 128) return raise(DCP_EMANYTHREADS, __func__); // THREAD_MAX, c-core/thread.h:7
+  int device = 0;
+  if (char const *d = getenv("DECIPHON_HIP_DEVICE")) device = atoi(d);
+  return setup_common(x, dbfile, device, 0, 1, multi_hits, hmmer3_compat, callback, userdata);
+}
+
+int dcp_scan_setup_partition(struct dcp_scan *x, char const *dbfile, int device, int index, int nparts,
+                             bool multi_hits, bool hmmer3_compat, void (*callback)(void *), void *userdata)
+{
+  return setup_common(x, dbfile, device, index, nparts, multi_hits, hmmer3_compat, callback, userdata);
+}
+
+int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *product_dir)
+{
+  if (!x || !batch || !product_dir) return raise(DCP_EFUNCUSE, __func__);
+  if (!x->eng) return raise(DCP_EFUNCUSE, __func__, "dcp_scan_setup has not succeeded");
+  x->done_proteins = 0;
+  x->interrupted = false;
+  x->products.clear();
+  int rc = 0;
+
+  // batch_encode (c-core/batch.c:60-70): every read goes to HBM once
+  int const nseq = (int)batch->seqs.size();
+  for (dcp_batch::Seq const &s : batch->seqs) // c-core/sequence.c:61-72
+  {
+    if (x->abc_name == "dna" && s.has_u) return raise(DCP_EDBDNASEQRNA, __func__);
+    if (x->abc_name == "rna" && s.has_t) return raise(DCP_EDBRNASEQDNA, __func__);
+  }
+  std::vector<int64_t> off((size_t)nseq + 1, 0);
+  for (int i = 0; i < nseq; ++i) off[(size_t)i + 1] = off[(size_t)i] + (int64_t)batch->seqs[(size_t)i].nt.size();
+  std::vector<uint8_t> nt((size_t)off[(size_t)nseq]);
+  for (int i = 0; i < nseq; ++i)
+    memcpy(nt.data() + off[(size_t)i], batch->seqs[(size_t)i].nt.data(), batch->seqs[(size_t)i].nt.size());
+  if ((rc = dcp_hip_set_sequences(x->eng, nseq, nt.data(), off.data()))) return raise(rc, __func__, dcp_hip_strerror(x->eng));
+
+  // product_open (c-core/product.c:14-32)
+  std::string const dir = product_dir;
+  if ((rc = mkdir_p(dir))) return raise(rc, __func__, product_dir);
+
+  std::vector<Row> rows;
+  int const nprof = dcp_hip_num_profiles(x->eng);
+  // profiles are walked in chunks so that the pair table stays small
+  size_t const max_pairs = 1u << 21;
+  int chunk = nseq > 0 ? (int)std::max<size_t>(1, max_pairs / (size_t)nseq) : nprof;
+  for (int p0 = 0; p0 < nprof && !x->interrupted; p0 += chunk)
+  {
+    int const p1 = std::min(nprof, p0 + chunk);
+    std::vector<Pair> pairs;
+    for (int p = p0; p < p1; ++p)
+      for (int s = 0; s < nseq; ++s)
+        if (!batch->seqs[(size_t)s].nt.empty())
+          pairs.emplace_back(p, s, (int)batch->seqs[(size_t)s].nt.size(), dcp_hip_profile_core_size(x->eng, p));
+    for (;;)
+    {
+      std::vector<dcp_hip_window> wins;
+      std::vector<size_t> owner;
+      for (size_t i = 0; i < pairs.size(); ++i)
+      {
+        Pair &pr = pairs[i];
+        if (!pr.active) continue;
+        if (!pr.win.next())
+        {
+          pr.active = false;
+          continue;
+        }
+        wins.push_back(dcp_hip_window{pr.profile, pr.seq, pr.win.start, pr.win.stop});
+        owner.push_back(i);
+      }
+      if (wins.empty()) break;
+      std::vector<float> nul(wins.size()), alt(wins.size());
+      if ((rc = dcp_hip_cost(x->eng, (int)wins.size(), wins.data(), nul.data(), alt.data())))
+        return raise(rc, __func__, dcp_hip_strerror(x->eng));
+
+      // c-core/thread.c:114-121
+      std::vector<dcp_hip_window> hits;
+      std::vector<size_t> hit_of;
+      std::vector<float> lrts;
+      for (size_t i = 0; i < wins.size(); ++i)
+      {
+        float const l = dcp_lrt(-nul[i], -alt[i]);
+        if (!isfinite(l) || l < 0) continue;
+        hits.push_back(wins[i]);
+        hit_of.push_back(i);
+        lrts.push_back(l);
+      }
+      // path pass in slices bounded by trellis memory: (L+1)*(2K+4) bytes each
+      size_t const budget = (size_t)8 << 30;
+      for (size_t h0 = 0; h0 < hits.size();)
+      {
+        size_t h1 = h0, bytes = 0;
+        while (h1 < hits.size())
+        {
+          size_t const L = (size_t)(hits[h1].stop - hits[h1].start);
+          size_t const K = (size_t)dcp_hip_profile_core_size(x->eng, hits[h1].profile);
+          size_t const b = (L + 1) * (2 * K + 4);
+          if (h1 > h0 && bytes + b > budget) break;
+          bytes += b;
+          ++h1;
+        }
+        if ((rc = dcp_hip_path(x->eng, (int)(h1 - h0), hits.data() + h0)))
+          return raise(rc, __func__, dcp_hip_strerror(x->eng));
+        for (size_t h = h0; h < h1; ++h)
+        {
+          int const n = dcp_hip_path_nsteps(x->eng, (int)(h - h0));
+          std::vector<int32_t> ids((size_t)n), sizes((size_t)n);
+          if ((rc = dcp_hip_path_steps(x->eng, (int)(h - h0), ids.data(), sizes.data()))) return raise(rc, __func__);
+          DcpHit hit;
+          if (!dcp_find_hit(ids, sizes, hit)) continue;
+          Pair &pr = pairs[owner[hit_of[h]]];
+          pr.win.last_hit_pos = hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
+          dcp_batch::Seq const &seq = batch->seqs[(size_t)pr.seq];
+          rows.push_back(Row{pr.profile, pr.seq, pr.win.idx,
+                             format_row(seq, pr.win.idx, pr.win.start, pr.win.stop, hit,
+                                        dcp_hip_profile_accession(x->eng, pr.profile), x->abc_name.c_str(),
+                                        lrts[h], ids, sizes)});
+        }
+        h0 = h1;
+      }
+      if (x->callback)
+        for (size_t i = 0; i < wins.size(); ++i) x->callback(x->userdata); // once per window, c-core/thread.c:74
+      if (x->interrupted) break;
+    }
+    x->done_proteins += p1 - p0;
+  }
+
+  // product_close (c-core/product.c:34-88): rows in profile, read, window order
+  std::stable_sort(rows.begin(), rows.end(), [](Row const &a, Row const &b) {
+    if (a.profile != b.profile) return a.profile < b.profile;
+    if (a.seq != b.seq) return a.seq < b.seq;
+    return a.window < b.window;
+  });
+  std::string const file = dir + "/products.tsv";
+  FILE *fp = fopen(file.c_str(), "wb");
+  if (!fp) return raise(DCP_EFOPEN, __func__, file.c_str());
+  bool ok = fputs("sequence\twindow\twindow_start\twindow_stop\thit\thit_start\thit_stop\tprofile\tabc\tlrt\tevalue\tmatch\n",
+                  fp) >= 0;
+  for (Row const &r : rows)
+  {
+    ok = ok && fputs(r.text.c_str(), fp) >= 0 && fputc('\n', fp) != EOF;
+    x->products.push_back(r.text);
+  }
+  if (fclose(fp) != 0 || !ok) return raise(DCP_EWRITEPROD, __func__, file.c_str());
+  return 0;
+}
+
+void dcp_scan_interrupt(struct dcp_scan *x)
+{
+  if (x) x->interrupted = true;
+}
+
+int dcp_scan_progress(struct dcp_scan const *x)
+{
+  if (!x || x->num_proteins <= 0) return 0;
+  return (100 * x->done_proteins.load()) / x->num_proteins; // c-core/scan.c:224-227
+}
+
+long dcp_scan_num_products(struct dcp_scan const *x) { return x ? (long)x->products.size() : 0; }
+
+char const *dcp_scan_product(struct dcp_scan const *x, long i)
+{
+  if (!x || i < 0 || i >= (long)x->products.size()) return nullptr;
+  return x->products[(size_t)i].c_str();
+}
+
+struct dcp_batch *dcp_batch_new(void) { return new (std::nothrow) dcp_batch; }
+
+void dcp_batch_del(struct dcp_batch *x) { delete x; }
+
+int dcp_batch_add(struct dcp_batch *x, long id, char const *name, char const *data)
+{
+  if (!x || !name || !data) return raise(DCP_EFUNCUSE, __func__);
+  dcp_batch::Seq s;
+  s.id = id;
+  s.name = name;
+  size_t const n = strlen(data);
+  s.nt.resize(n);
+  int rc = dcp_encode_sequence(data, (int64_t)n, s.nt.data());
+  if (rc) return raise(rc, __func__);
+  s.text.resize(n);
+  for (size_t i = 0; i < n; ++i) s.text[i] = "ACGT"[s.nt[i]];
+  // the reference keeps U as U in the stored text (c-core/disambiguate.c:14-21)
+  for (size_t i = 0; i < n; ++i)
+  {
+    s.has_u = s.has_u || data[i] == 'U' || data[i] == 'u';
+    s.has_t = s.has_t || data[i] == 'T' || data[i] == 't';
+  }
+  if (s.has_u)
+    for (size_t i = 0; i < n; ++i)
+      if (s.text[i] == 'T') s.text[i] = 'U';
+  x->seqs.push_back(std::move(s));
+  return 0;
+}
+
+void dcp_batch_reset(struct dcp_batch *x)
+{
+  if (x) x->seqs.clear();
+}
+
+// ---- press: not provided (needs third-party imm + hmmer_reader) ----------------
+struct dcp_press *dcp_press_new(void) { return new (std::nothrow) dcp_press; }
+int dcp_press_setup(struct dcp_press *, int, float) { return raise(DCP_EFUNCUSE, __func__, "press is not part of this build"); }
+int dcp_press_open(struct dcp_press *, char const *, char const *) { return raise(DCP_EFUNCUSE, __func__, "press is not part of this build"); }
+long dcp_press_nproteins(struct dcp_press const *) { return 0; }
+int dcp_press_next(struct dcp_press *) { return raise(DCP_EFUNCUSE, __func__, "press is not part of this build"); }
+bool dcp_press_end(struct dcp_press const *) { return true; }
+int dcp_press_close(struct dcp_press *) { return 0; }
+void dcp_press_del(struct dcp_press const *x) { delete const_cast<dcp_press *>(x); }
+
+} // extern "C"

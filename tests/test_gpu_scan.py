@@ -1,0 +1,152 @@
+"""GPU: the reference's outer API (dcp_scan_* / dcp_batch_*, include/deciphon.h) through the
+Python mirror of python-core's Scan/Batch classes -- the shape of python-core/tests/test_scan.py
+and c-core/test_scan.c, test_window.c.  Expected rows come from the reference's committed
+products.tsv (minus the HMMER e-value and the imm-decoded codon/amino fields, which are out
+of scope) and from an oracle-driven restatement of thread_run."""
+import os
+
+import numpy as np
+import pytest
+
+from dcp_testlib import GOLDEN, read_fasta
+from oracle.dcp_reader import read_dcp
+
+pytestmark = pytest.mark.gpu
+
+DCP = os.path.join(GOLDEN, "minifam.dcp")
+
+
+def oracle_scan(orc, db, reads, multi_hits, hmmer3_compat):
+    """thread_run + process_window (c-core/thread.c:49-207) on the CPU oracle, without HMMER."""
+    rows = []
+    for prot in db.proteins:
+        prof = orc.setup_profile(prot)
+        for sid, text in reads:
+            x = orc.encode(text)
+            state = {"last": None}
+
+            def hook(idx):
+                return state["last"]
+
+            w = orc.lib.orc_window_setup(len(x), prof.K)
+            import ctypes as C
+
+            while orc.lib.orc_window_next(C.byref(w)):
+                seq = np.ascontiguousarray(x[w.start : w.stop])
+                xt = orc.xtrans(max(len(seq) // 3, 1), multi_hits, hmmer3_compat)
+                lrt = orc.lrt(-orc.null(prof, xt, seq), -orc.cost(prof, xt, seq))
+                if not np.isfinite(lrt) or lrt < 0:
+                    continue
+                _, xn, nd = orc.path(prof, xt, seq)
+                ids, sizes = orc.unzip(prof.K, len(seq), xn, nd)
+                hit, last = orc.hits(ids, sizes)
+                if hit is None:
+                    continue
+                w.last_hit_pos = last
+                pos, cells = hit[0], []
+                for st, sz in zip(ids[hit[2] : hit[3]], sizes[hit[2] : hit[3]]):
+                    cells.append(f"{text[w.start + pos : w.start + pos + sz]},{orc.state_name(st)},,")
+                    pos += sz
+                rows.append(f"{sid}\t{w.idx}\t{w.start}\t{w.stop}\t0\t{hit[0]}\t{hit[1]}\t{prot.accession}\tdna\t"
+                            f"{lrt:.1f}\tnan\t" + ";".join(cells))
+    return rows
+
+
+def run_scan(tmp_path, reads, multi_hits=True, hmmer3_compat=False, **kw):
+    from deciphon_amd.scan import Batch, Scan, Sequence
+
+    batch = Batch()
+    for sid, text in reads:
+        batch.add(Sequence(sid, f"seq{sid}", text))
+    with Scan(DCP, 0, 1, multi_hits, hmmer3_compat, False, **kw) as scan:
+        scan.run(tmp_path, batch)
+        assert scan.progress() == 100
+        rows = scan.products()
+    lines = open(os.path.join(tmp_path, "products.tsv")).read().splitlines()
+    assert lines[0].split("\t") == ["sequence", "window", "window_start", "window_stop", "hit", "hit_start",
+                                    "hit_stop", "profile", "abc", "lrt", "evalue", "match"]
+    assert lines[1:] == rows
+    return rows
+
+
+def test_consensus_scan_matches_reference_products(tmp_path, orc):
+    """control/tests/files/consensus.fna x minifam.dcp == control/tests/files/snap.dcs."""
+    reads = [(i, s) for i, (_, s) in enumerate(read_fasta(os.path.join(GOLDEN, "consensus.fna")))]
+    rows = run_scan(str(tmp_path), reads)
+    gold = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(GOLDEN, "products.tsv"))][1:]
+    assert len(rows) == len(gold) == 3
+    for got, want in zip(rows, gold):
+        g = got.split("\t")
+        assert g[:10] == want[:10]  # sequence .. lrt, byte for byte
+        assert [c.split(",")[:2] for c in g[11].split(";")] == [c.split(",")[:2] for c in want[11].split(";")]
+
+
+@pytest.mark.parametrize("multi_hits,hmmer3_compat", [(True, False), (False, False), (True, True), (False, True)])
+def test_all_reads_all_modes_against_oracle_scan(tmp_path, orc, multi_hits, hmmer3_compat):
+    """The 8 reads of c-core/test_consensus.h x the 4 mode combinations of c-core/test_scan.c:15-16."""
+    named = read_fasta(os.path.join(GOLDEN, "consensus.fna")) + read_fasta(os.path.join(GOLDEN, "consensus_multi.fna"))
+    reads = [(i + 1, s) for i, (_, s) in enumerate(named)]
+    rows = run_scan(str(tmp_path), reads, multi_hits, hmmer3_compat)
+    assert rows == oracle_scan(orc, read_dcp(DCP), reads, multi_hits, hmmer3_compat)
+    assert len(rows) >= 8
+
+
+def test_sliding_windows_chain_like_test_window(tmp_path, orc):
+    """c-core/test_window.c:25-37: a long read made of consensus copies with 70 % of the
+    positions randomised, scanned through chained windows (window = 50*K nt)."""
+    rng = np.random.default_rng(31)
+    cons = read_fasta(os.path.join(GOLDEN, "consensus.fna"))[0][1]
+    text = list((cons * 40)[:20000])
+    for i in range(len(text)):
+        if rng.random() < 0.7:
+            text[i] = "ACGT"[rng.integers(0, 4)]
+    # keep a few intact copies so that some windows do hit
+    for at in (1500, 9000, 16500):
+        text[at : at + len(cons)] = cons
+    reads = [(7, "".join(text)), (8, cons[:100]), (9, "ACGTN" * 50)]
+    rows = run_scan(str(tmp_path), reads)
+    want = oracle_scan(orc, read_dcp(DCP), reads, True, False)
+    assert rows == want
+    assert any(r.split("\t")[1] != "0" for r in rows)  # a hit in a later window
+
+
+def test_partitions_concatenate_to_the_whole_scan(tmp_path, orc):
+    """Contiguous profile partitions (c-core/partition_size.c) scanned separately give, in
+    partition order, exactly the rows of the unpartitioned scan (c-core/product.c:63-81)."""
+    named = read_fasta(os.path.join(GOLDEN, "consensus.fna"))
+    reads = [(i, s) for i, (_, s) in enumerate(named)]
+    whole = run_scan(str(tmp_path / "w"), reads)
+    parts = []
+    for idx in range(2):
+        parts += run_scan(str(tmp_path / f"p{idx}"), reads, partition=(0, idx, 2))
+    assert parts == whole
+    more = []
+    for idx in range(5):  # more partitions than profiles: the surplus ones are empty
+        d = tmp_path / f"q{idx}"
+        more += run_scan(str(d), reads, partition=(0, idx, 5)) if idx < 3 else []
+    assert more == whole
+
+
+def test_errors_and_interrupt(tmp_path):
+    from deciphon_amd.scan import Batch, DeciphonError, Scan, Sequence
+
+    with pytest.raises(DeciphonError) as e:
+        Scan(str(tmp_path / "nope.dcp"), 0, 1, True, False, False)
+    assert e.value.code == 21  # DCP_EOPENDB
+    b = Batch()
+    with pytest.raises(DeciphonError) as e:
+        b.add(Sequence(1, "bad", "ACGTU"))
+    assert e.value.code == 74  # DCP_ENUCLTSEQTU
+    b.add(Sequence(2, "rna", "ACGUACGU"))
+    with Scan(DCP, 0, 1, True, False, False) as scan:
+        with pytest.raises(DeciphonError) as e:
+            scan.run(str(tmp_path), b)
+        assert e.value.code == 72  # DCP_EDBDNASEQRNA
+    cons = read_fasta(os.path.join(GOLDEN, "consensus.fna"))[0][1]
+    b = Batch()
+    b.add(Sequence(3, "ok", cons))
+    calls = []
+    scan = Scan(DCP, 0, 1, True, False, False, on_window=lambda: calls.append(1))
+    with scan:
+        scan.run(str(tmp_path), b)
+        assert len(calls) == 3  # one callback per window: 3 profiles x 1 read x 1 window
