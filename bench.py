@@ -98,6 +98,18 @@ def cpu_baseline(db, reads, cores, budget_s=15.0):
                       f"viterbi_null+viterbi_cost per window, {secs:.1f} s on {used} host thread(s)"}
 
 
+def measured_traffic():
+    """HBM bytes per step from the newest committed PMC summary (scripts/profile_bench.sh writes
+    profiles/*_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc passes)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    t = json.load(open(files[-1]))
+    return t.get("hbm_bytes_per_step"), os.path.basename(files[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,24 +122,19 @@ def main():
 
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     import deciphon_amd
+    from deciphon_amd import dist as ddist
     from dcp_testlib import GOLDEN
     from oracle.dcp_reader import read_dcp
+
+    rank, local_rank, world = ddist.init_process_group("cuda")
+    dist = torch.distributed if world > 1 else None
+    dev = f"cuda:{local_rank}"
 
     dcp = os.path.join(GOLDEN, "minifam.dcp")
     db = read_dcp(dcp)
     consensus = [p.consensus for p in db.proteins]
-    reads = synth_reads(args.reads, args.read_len, consensus, rank)
+    reads = synth_reads(args.reads, args.read_len, consensus, rank)  # every rank scores its own reads
 
     eng = deciphon_amd.Engine(local_rank)
     eng.load_dcp(dcp)
@@ -136,6 +143,7 @@ def main():
     eng.set_mode(True, False)
     nprof = eng.num_profiles
     wins = [(p, s, 0, len(reads[s])) for p in range(nprof) for s in range(len(reads))]
+    eng.stage(wins)  # inputs resident in HBM before the timed region
 
     def barrier():
         torch.cuda.synchronize()
@@ -143,30 +151,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    eng.run_staged(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    # warm-up launches are untimed inside cost_bench; the HIP-event time covers exactly `steps` launches
-    ms, cells, nul, alt = eng.cost_bench(wins, args.warmup, args.steps)
+    ms, cells = eng.run_staged(args.steps)  # returns when the last launch has finished
     barrier()
     wall = time.perf_counter() - t0
-    kernel_s = ms * 1e-3 * args.steps
 
-    t = torch.tensor([kernel_s], dtype=torch.float64, device=f"cuda:{local_rank}")
-    c = torch.tensor([cells], dtype=torch.float64, device=f"cuda:{local_rank}")
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    c = torch.tensor([cells], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        # the path's only exchange: hit records (lrt >= 0) gathered to every rank over RCCL
-        lrt = -2.0 * ((-nul) - (-alt))
-        hits = torch.tensor([int((lrt >= 0).sum())], dtype=torch.int64, device=f"cuda:{local_rank}")
-        gathered = [torch.zeros_like(hits) for _ in range(world)]
-        dist.all_gather(gathered, hits)
-    t_max = float(t.item())
-    total_cells = float(c.item())
+    t_max, total_cells = float(t.item()), float(c.item())
+
+    # the path's only exchange, after the timed region: hit records gathered over RCCL
+    nul, alt = eng.fetch_staged()
+    lrt = -2.0 * ((-nul) - (-alt))
+    rows = [f"{rank}\t{wins[i][0]}\t{wins[i][1]}\t{lrt[i]:.1f}" for i in np.nonzero(lrt >= 0)[0]]
+    all_rows = ddist.gather_rows(rows, dev)
 
     if rank == 0:
         gcups = total_cells * args.steps / t_max / 1e9
-        per_gpu_gbps = (cells * BYTES_PER_CELL) / (ms * 1e-3) / 1e9
+        kernel_ms = ms / args.steps
+        per_gpu_gbps = (cells * BYTES_PER_CELL) / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic()
         out = {
             "metric": "GCUPS (Viterbi DP cell updates/sec)", "value": gcups, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
@@ -175,18 +184,22 @@ def main():
             "config": {"workload": f"minifam.dcp (K=173,241,162) x {args.reads} synthetic {args.read_len} nt reads "
                                    f"per GPU, one window per pair, viterbi_null+viterbi_cost",
                        "profiles": nprof, "reads_per_gpu": args.reads, "read_len": args.read_len,
+                       "hits_gathered": len(all_rows),
                        "parallelism": f"reads sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": per_gpu_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": per_gpu_gbps / HBM_PEAK_GBPS, "traffic": None,
-                         "note": "algorithmic 20 B/cell; emission rows are re-read from L2, so frac may exceed "
-                                 "the HBM share; see DESIGN.md"},
-            "wall_s_incl_staging": wall,
+                         "frac": per_gpu_gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel_ms_per_step": kernel_ms, "traffic_source": traffic_src,
+                         "note": "achieved = 20 B/cell (SURVEY 8d) x cells of one step / HIP-event time of one "
+                                 "step on the engine's stream; operands are re-read from L2, so frac can exceed "
+                                 "the HBM share (traffic = measured HBM bytes per step); the binding limit is "
+                                 "instruction issue, see DESIGN.md section 5"},
         }
         if not args.no_cpu_baseline:
             cores = min(os.cpu_count() or 1, 16)
             out["cpu_baseline"] = cpu_baseline(db, reads, cores)
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -111,6 +111,10 @@ struct dcp_hip
   DevBuf<unsigned char> d_arena;
   std::vector<unsigned char> host_arena;
   std::vector<PathResult> paths;
+  std::vector<DcpProblem> staged_problems; // dcp_hip_stage
+  int staged_c_begin[DCP_NUM_CLASSES + 1] = {0};
+  double staged_cells = 0;
+  int staged_n = -1;
 };
 
 namespace
@@ -209,6 +213,7 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, bool with_trellis, Staged 
   if (i != n) return fail(x, DCP_ELARGECORESIZE, "profile outside every kernel class");
   int rc = ensure_xt(x, max_s + 1);
   if (rc) return rc;
+  x->staged_n = -1; // the device problem list is about to be replaced
   HIP_TRY(x, x->d_problems.reserve((size_t)std::max(n, 1)), DCP_ENOMEM);
   if (n)
     HIP_TRY(x, hipMemcpyAsync(x->d_problems.p, st.problems.data(), (size_t)n * sizeof(DcpProblem),
@@ -576,6 +581,61 @@ int dcp_hip_cost_bench(struct dcp_hip *x, int n, struct dcp_hip_window const *w,
       null_cost[i] = out[2 * (size_t)i];
       alt_cost[i] = out[2 * (size_t)i + 1];
     }
+  }
+  return 0;
+}
+
+int dcp_hip_stage(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
+{
+  if (!x || n <= 0) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  Staged st;
+  int rc = stage(x, n, w, false, st);
+  if (rc) return rc;
+  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  memcpy(x->staged_c_begin, st.c_begin, sizeof(st.c_begin));
+  x->staged_cells = st.cells;
+  x->staged_n = n;
+  return 0;
+}
+
+int dcp_hip_run_staged(struct dcp_hip *x, int reps, float *ms, double *cells)
+{
+  if (!x || x->staged_n <= 0 || reps < 0) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  Staged st;
+  memcpy(st.c_begin, x->staged_c_begin, sizeof(st.c_begin));
+  hipEvent_t e0, e1;
+  HIP_TRY(x, hipEventCreate(&e0), DCP_EFUNCUSE);
+  HIP_TRY(x, hipEventCreate(&e1), DCP_EFUNCUSE);
+  HIP_TRY(x, hipEventRecord(e0, x->stream), DCP_EFUNCUSE);
+  int rc = 0;
+  for (int i = 0; i < reps && !rc; ++i) rc = launch_cost_all(x, st);
+  if (rc) return rc;
+  HIP_TRY(x, hipEventRecord(e1, x->stream), DCP_EFUNCUSE);
+  HIP_TRY(x, hipEventSynchronize(e1), DCP_EFUNCUSE);
+  float total = 0;
+  HIP_TRY(x, hipEventElapsedTime(&total, e0, e1), DCP_EFUNCUSE);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (ms) *ms = total;
+  if (cells) *cells = x->staged_cells;
+  return 0;
+}
+
+int dcp_hip_fetch_staged(struct dcp_hip *x, float *null_cost, float *alt_cost)
+{
+  if (!x || x->staged_n <= 0 || !null_cost || !alt_cost) return DCP_EFUNCUSE;
+  size_t const n = (size_t)x->staged_n;
+  std::vector<float> out(2 * n);
+  HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  for (size_t i = 0; i < n; ++i)
+  {
+    null_cost[i] = out[2 * i];
+    alt_cost[i] = out[2 * i + 1];
   }
   return 0;
 }

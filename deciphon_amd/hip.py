@@ -67,6 +67,9 @@ def load_library() -> C.CDLL:
     L.dcp_hip_xtrans.restype = None
     L.dcp_hip_cost.argtypes = [vp, i32, vp, vp, vp]
     L.dcp_hip_cost_bench.argtypes = [vp, i32, vp, i32, i32, f32p, C.POINTER(C.c_double), vp, vp]
+    L.dcp_hip_stage.argtypes = [vp, i32, vp]
+    L.dcp_hip_run_staged.argtypes = [vp, i32, f32p, C.POINTER(C.c_double)]
+    L.dcp_hip_fetch_staged.argtypes = [vp, vp, vp]
     L.dcp_hip_path.argtypes = [vp, i32, vp]
     L.dcp_hip_path_nsteps.argtypes = [vp, i32]
     L.dcp_hip_path_steps.argtypes = [vp, i32, vp, vp]
@@ -228,6 +231,25 @@ class Engine:
         self._check(self.lib.dcp_hip_cost_bench(self.h, n, arr, warmup, reps, C.byref(ms), C.byref(cells), _p(nul),
                                                 _p(alt)))
         return ms.value, cells.value, nul, alt
+
+    def stage(self, windows) -> None:
+        """Copies the window list to HBM for run_staged() (measurement)."""
+        n, arr = self._windows(windows)
+        self._staged_n = n
+        self._check(self.lib.dcp_hip_stage(self.h, n, arr))
+
+    def run_staged(self, reps: int):
+        """-> (HIP-event ms of `reps` cost-pass launches together, DP cells of one launch)."""
+        ms = C.c_float(0)
+        cells = C.c_double(0)
+        self._check(self.lib.dcp_hip_run_staged(self.h, reps, C.byref(ms), C.byref(cells)))
+        return ms.value, cells.value
+
+    def fetch_staged(self):
+        nul = np.zeros(self._staged_n, dtype=np.float32)
+        alt = np.zeros(self._staged_n, dtype=np.float32)
+        self._check(self.lib.dcp_hip_fetch_staged(self.h, _p(nul), _p(alt)))
+        return nul, alt
 
     def path(self, windows):
         """-> list of dicts(score, state_ids, seqsizes, xnodes, nodes) -- viterbi_path + trellis_unzip."""

@@ -117,6 +117,13 @@ float dcp_hip_path_score(struct dcp_hip const *, int i);
  * launch, *cells the DP cells (sum of K*L) one launch computes. */
 int dcp_hip_cost_bench(struct dcp_hip *, int n, struct dcp_hip_window const *, int warmup, int reps,
                        float *ms, double *cells, float *null_cost, float *alt_cost);
+/* The same in two steps: dcp_hip_stage copies the window list to HBM (untimed);
+ * dcp_hip_run_staged launches the cost pass `reps` times over it and returns when the
+ * last launch has finished; *ms = HIP-event time of all `reps` launches together,
+ * *cells = DP cells of ONE launch.  dcp_hip_fetch_staged copies the scores back. */
+int dcp_hip_stage(struct dcp_hip *, int n, struct dcp_hip_window const *);
+int dcp_hip_run_staged(struct dcp_hip *, int reps, float *ms, double *cells);
+int dcp_hip_fetch_staged(struct dcp_hip *, float *null_cost, float *alt_cost);
 
 #ifdef __cplusplus
 }

@@ -47,3 +47,33 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
         print(f"[{os.path.basename(d)}] {k} dispatches={n}")
         for c, v in sorted(acc[k].items()):
             print(f"    {c:36s} total={v:18.1f} per_dispatch={v / n:16.1f}")
+
+# HBM traffic per bench step (all dispatches of the Viterbi kernels in one step), for bench.py.
+# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide
+# coalesced reads (MI355X_MICROARCH.md, HBM), so the read side is doubled as that guide prescribes.
+import json
+import re
+
+fetch = write = 0.0
+steps = None
+for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        per_kernel = defaultdict(set)
+        for r in csv.DictReader(open(f)):
+            if "dcp_cost_kernel" not in r["Kernel_Name"] and "dcp_path_kernel" not in r["Kernel_Name"]:
+                continue
+            per_kernel[r["Kernel_Name"]].add(r["Dispatch_Id"])
+            if r["Counter_Name"] == "FETCH_SIZE":
+                fetch += float(r["Counter_Value"])
+            if r["Counter_Name"] == "WRITE_SIZE":
+                write += float(r["Counter_Value"])
+        if per_kernel:
+            steps = max(len(v) for v in per_kernel.values())
+if steps:
+    tag = os.path.basename(os.path.normpath(out))
+    rec = {"fetch_kib_raw_per_step": fetch / steps, "write_kib_per_step": write / steps,
+           "hbm_bytes_per_step": (2.0 * fetch + write) * 1024.0 / steps, "dispatches_per_kernel": steps,
+           "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); separate --pmc passes"}
+    dst = os.path.join(out, tag + "_traffic.json")  # copy it to profiles/ to have bench.py report it
+    json.dump(rec, open(dst, "w"), indent=1)
+    print("== traffic ==", json.dumps(rec))
