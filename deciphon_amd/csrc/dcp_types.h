@@ -14,26 +14,32 @@ enum { DCP_RR, DCP_SN, DCP_NN, DCP_SB, DCP_NB, DCP_EB, DCP_JB, DCP_EJ, DCP_JJ, D
 
 // One sequence position: codes of the 1..5-mers that END at this position,
 // i.e. code_fn(pos - t, t) for t = 1..5 in c[t-1] (0 where the t-mer would start
-// before the sequence).  16 bytes so that a DP row costs one scalar dwordx4 load.
+// before the sequence).  32 bytes, one code per dword, so that a DP row costs one
+// scalar dwordx8 load and no unpacking.
 struct DcpCodeRow
 {
-  uint16_t c[8];
+  uint32_t c[8];
 };
+
+#define DCP_ROW_HDR 4 // floats in front of every emission row: null[c], bg[c], 0, 0
 
 // A profile resident in HBM, in DP-parameter space (costs = -log-prob, +inf =
 // impossible), padded to Kp = 64*Q*W positions with +inf.  All arrays live in
 // one device pool of floats; the fields are offsets into it (in floats), so that
 // kernels address them as kernel-argument base + scalar offset.
+//   rows : 1364 emission rows, code-major, each DCP_ROW_HDR + Kp floats:
+//          { null[c], bg[c], 0, 0, match[c][0..Kp) } -- everything a DP row needs
+//          for one emission length sits behind ONE scalar offset c * stride
+//   trans: [8][Kp]
 struct DcpProfileDev
 {
   int32_t K;         // core size
-  int32_t Kp;        // padded row length in floats
+  int32_t Kp;        // padded positions
   int32_t Q;         // positions per lane
   int32_t W;         // waves per problem (1 for K <= 256)
-  int64_t match_off; // [1364][Kp] code-major match emissions
+  int64_t rows_off;  // [1364][DCP_ROW_HDR + Kp]
   int64_t trans_off; // [8][Kp]
-  int64_t null_off;  // [1364]
-  int64_t bg_off;    // [1364]
+  int64_t pad0, pad1;
 };
 
 // One (profile x sequence-window) DP problem.

@@ -2,10 +2,10 @@
 //
 // HBM layout (one engine = one GPU):
 //   pool      float[]          all profiles back to back; per profile
-//                              match[1364][Kp] | trans[8][Kp] | null[1364] | bg[1364],
-//                              Kp = 64*Q, padding = +inf (DcpProfileDev holds the offsets)
+//                              rows[1364][4+Kp] = {null, bg, 0, 0, match[0..Kp)} | trans[8][Kp],
+//                              Kp = 64*Q*W, padding = +inf (DcpProfileDev holds the offsets)
 //   profiles  DcpProfileDev[]
-//   code_rows DcpCodeRow[]     per sequence len+1 rows of 16 B (built on the GPU
+//   code_rows DcpCodeRow[]     per sequence len+1 rows of 32 B (built on the GPU
 //                              from 1 B/nt by dcp_encode_kernel)
 //   xt_table  float[S+1][16]   special transitions per amino length S (host-computed:
 //                              they need double-precision log, c-core/xtrans.c:26-45)
@@ -320,8 +320,7 @@ void dcp_hip_del(struct dcp_hip *x)
 
 char const *dcp_hip_strerror(struct dcp_hip const *x) { return x ? x->err.c_str() : "no engine"; }
 
-static int add_slot(dcp_hip *x, int K, char const *accession, float **trans, float **match, float **nul, float **bg,
-                    int *index)
+static int add_slot(dcp_hip *x, int K, char const *accession, float **trans, float **rows, int *index)
 {
   if (K < 1 || K > DCP_MODEL_MAX) return fail(x, DCP_ELARGECORESIZE, "core size out of range");
   int const cls = dcp_class_of(K);
@@ -333,15 +332,14 @@ static int add_slot(dcp_hip *x, int K, char const *accession, float **trans, flo
   hp.Kp = 64 * hp.Q * hp.W;
   hp.pool_off = (int64_t)x->pool.size();
   hp.accession = accession ? accession : "";
-  size_t const floats = (size_t)(DCP_TABLE_SIZE + DCP_NUM_TRANS) * hp.Kp + 2 * DCP_TABLE_SIZE;
+  size_t const stride = (size_t)hp.Kp + DCP_ROW_HDR;
+  size_t const floats = (size_t)DCP_TABLE_SIZE * stride + (size_t)DCP_NUM_TRANS * hp.Kp;
   // keep every profile 16-byte aligned for the dwordx4 row loads
   size_t const padded = (floats + 3) & ~(size_t)3;
   x->pool.resize(x->pool.size() + padded, INFINITY);
   float *base = x->pool.data() + hp.pool_off;
-  *match = base;
-  *trans = base + (size_t)DCP_TABLE_SIZE * hp.Kp;
-  *nul = *trans + (size_t)DCP_NUM_TRANS * hp.Kp;
-  *bg = *nul + DCP_TABLE_SIZE;
+  *rows = base;
+  *trans = base + (size_t)DCP_TABLE_SIZE * stride;
   if (index) *index = (int)x->profiles.size();
   x->profiles.push_back(hp);
   return 0;
@@ -351,14 +349,20 @@ int dcp_hip_add_profile(struct dcp_hip *x, int K, float const *trans, float cons
                         float const *bg_cost, int *index)
 {
   if (!x || !trans || !match || !null_cost || !bg_cost) return DCP_EFUNCUSE;
-  float *t, *m, *n, *b;
-  int rc = add_slot(x, K, nullptr, &t, &m, &n, &b, index);
+  float *t, *r;
+  int rc = add_slot(x, K, nullptr, &t, &r, index);
   if (rc) return rc;
   int const Kp = x->profiles.back().Kp;
+  size_t const stride = (size_t)Kp + DCP_ROW_HDR;
   for (int id = 0; id < DCP_NUM_TRANS; ++id) memcpy(t + (size_t)id * Kp, trans + (size_t)id * K, sizeof(float) * K);
-  for (int c = 0; c < DCP_TABLE_SIZE; ++c) memcpy(m + (size_t)c * Kp, match + (size_t)c * K, sizeof(float) * K);
-  memcpy(n, null_cost, sizeof(float) * DCP_TABLE_SIZE);
-  memcpy(b, bg_cost, sizeof(float) * DCP_TABLE_SIZE);
+  for (int c = 0; c < DCP_TABLE_SIZE; ++c)
+  {
+    float *hdr = r + (size_t)c * stride;
+    hdr[0] = null_cost[c];
+    hdr[1] = bg_cost[c];
+    hdr[2] = hdr[3] = 0.0f;
+    memcpy(hdr + DCP_ROW_HDR, match + (size_t)c * K, sizeof(float) * K);
+  }
   return 0;
 }
 
@@ -366,10 +370,10 @@ int dcp_hip_add_protein(struct dcp_hip *x, int K, float const *node_trans, float
                         float const *BMk, float const *null_lprob, float const *bg_lprob, int *index)
 {
   if (!x || !node_trans || !node_emission || !BMk || !null_lprob || !bg_lprob) return DCP_EFUNCUSE;
-  float *t, *m, *n, *b;
-  int rc = add_slot(x, K, nullptr, &t, &m, &n, &b, index);
+  float *t, *r;
+  int rc = add_slot(x, K, nullptr, &t, &r, index);
   if (rc) return rc;
-  dcp_setup_profile(K, x->profiles.back().Kp, node_trans, node_emission, BMk, null_lprob, bg_lprob, t, m, n, b);
+  dcp_setup_profile(K, x->profiles.back().Kp, node_trans, node_emission, BMk, null_lprob, bg_lprob, t, r);
   return 0;
 }
 
@@ -386,10 +390,10 @@ int dcp_hip_load_dcp(struct dcp_hip *x, char const *path, int first, int count)
   for (int i = first; i < last; ++i)
   {
     if ((rc = db.read_protein(i, p))) return fail(x, rc, "cannot read protein");
-    float *t, *m, *n, *b;
-    if ((rc = add_slot(x, p.core_size, p.accession.c_str(), &t, &m, &n, &b, nullptr))) return rc;
+    float *t, *r;
+    if ((rc = add_slot(x, p.core_size, p.accession.c_str(), &t, &r, nullptr))) return rc;
     dcp_setup_profile(p.core_size, x->profiles.back().Kp, p.trans.data(), p.emission.data(), p.BMk.data(),
-                      p.null_emission.data(), p.bg_emission.data(), t, m, n, b);
+                      p.null_emission.data(), p.bg_emission.data(), t, r);
   }
   return 0;
 }
@@ -427,10 +431,9 @@ int dcp_hip_commit_profiles(struct dcp_hip *x)
     dev[i].Kp = hp.Kp;
     dev[i].Q = hp.Q;
     dev[i].W = hp.W;
-    dev[i].match_off = hp.pool_off;
-    dev[i].trans_off = dev[i].match_off + (int64_t)DCP_TABLE_SIZE * hp.Kp;
-    dev[i].null_off = dev[i].trans_off + (int64_t)DCP_NUM_TRANS * hp.Kp;
-    dev[i].bg_off = dev[i].null_off + DCP_TABLE_SIZE;
+    dev[i].rows_off = hp.pool_off;
+    dev[i].trans_off = dev[i].rows_off + (int64_t)DCP_TABLE_SIZE * (hp.Kp + DCP_ROW_HDR);
+    dev[i].pad0 = dev[i].pad1 = 0;
   }
   HIP_TRY(x, x->d_profiles.reserve(dev.size()), DCP_ENOMEM);
   HIP_TRY(x, hipMemcpyAsync(x->d_profiles.p, dev.data(), dev.size() * sizeof(DcpProfileDev), hipMemcpyHostToDevice,

@@ -54,8 +54,7 @@ void dcp_xtrans(int seq_size, bool multi_hits, bool hmmer3_compat, float xt[DCP_
 }
 
 void dcp_setup_profile(int K, int Kp, float const *node_trans, float const *node_emission, float const *BMk,
-                       float const *null_lprob, float const *bg_lprob, float *trans, float *match, float *null_cost,
-                       float *bg_cost)
+                       float const *null_lprob, float const *bg_lprob, float *trans, float *rows)
 {
   for (size_t i = 0; i < (size_t)DCP_NUM_TRANS * Kp; ++i) trans[i] = INFINITY; // viterbi_setup fills +inf
   for (int k = 0; k < K; ++k) trans[DCP_BM * Kp + k] = -BMk[k];
@@ -73,11 +72,14 @@ void dcp_setup_profile(int K, int Kp, float const *node_trans, float const *node
   trans[DCP_MI * Kp + K - 1] = INFINITY;
   trans[DCP_II * Kp + K - 1] = INFINITY;
   // node-major [k][code] on disk -> code-major [code][k] rows for the kernels
+  size_t const stride = (size_t)Kp + DCP_ROW_HDR;
   for (int c = 0; c < DCP_TABLE_SIZE; ++c)
   {
-    null_cost[c] = -null_lprob[c];
-    bg_cost[c] = -bg_lprob[c];
-    float *row = match + (size_t)c * Kp;
+    float *hdr = rows + (size_t)c * stride;
+    hdr[0] = -null_lprob[c];
+    hdr[1] = -bg_lprob[c];
+    hdr[2] = hdr[3] = 0.0f;
+    float *row = hdr + DCP_ROW_HDR;
     for (int k = 0; k < K; ++k) row[k] = -node_emission[(size_t)k * DCP_TABLE_SIZE + c];
     for (int k = K; k < Kp; ++k) row[k] = INFINITY;
   }

@@ -11,10 +11,10 @@
 void dcp_xtrans(int seq_size, bool multi_hits, bool hmmer3_compat, float xt[DCP_NUM_XTRANS]);
 
 // c-core/protein.c:353-394 (protein_setup_viterbi): node-major log-probs ->
-// DP cost arrays padded to Kp columns with +inf.  trans[8][Kp], match[1364][Kp].
+// DP costs in the device layout, padded to Kp columns with +inf: trans[8][Kp] and
+// rows[1364][DCP_ROW_HDR + Kp] = { null, bg, 0, 0, match[0..Kp) }.
 void dcp_setup_profile(int K, int Kp, float const *node_trans, float const *node_emission, float const *BMk,
-                       float const *null_lprob, float const *bg_lprob, float *trans, float *match, float *null_cost,
-                       float *bg_cost);
+                       float const *null_lprob, float const *bg_lprob, float *trans, float *rows);
 
 // c-core/sequence.c:15-45 (uppercase + disambiguate, c-core/disambiguate.c:37-86)
 // followed by the A,C,G,T/U -> 0..3 indexing imm_eseq applies.  0 or DCP_E*.

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dcp_types.h"
+
 #define DCP_FN __device__ __forceinline__
 #define DCP_WAVE 64
 
@@ -41,6 +43,25 @@ DCP_FN lf lane_shift_up(lf x, float fill)
 {
   return __int_as_float(
       __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
+}
+
+// The same into a register that is kept across rows: wave_shr:1 never writes lane 0,
+// so once lane 0 of `keep` holds the fill value it stays there and no constant has to
+// be re-materialised per shift.
+DCP_FN lf lane_shift_up_keep(lf x, lf &keep)
+{
+  keep = __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(x), 0x138, 0xf, 0xf, false));
+  return keep;
+}
+
+// a uniform value the compiler must hold in a VGPR (so that VALU ops can pair it with
+// an SGPR operand instead of copying the SGPR first)
+DCP_FN lf lf_pin(float x)
+{
+  lf v = x;
+  asm volatile("" : "+v"(v));
+  return v;
 }
 
 // min over the 64 lanes, returned to every lane (uniform).  DPP row_shr 1,2,4,8
@@ -104,6 +125,7 @@ template <> struct Group<1>
   DCP_FN void put_count(int, lm) {}
   DCP_FN void sync() {}
   DCP_FN lf get_shift(int, lf x, float fill) { return lane_shift_up(x, fill); }
+  DCP_FN lf get_shift_keep(int, lf x, lf &keep) { return lane_shift_up_keep(x, keep); }
   DCP_FN float get_min(int, lf x) { return wave_min(x); }
   DCP_FN uint32_t get_minu(int, lu x) { return wave_minu(x); }
   DCP_FN float get_lane(int, lf x, int l) { return read_lane(x, l); }
@@ -159,6 +181,7 @@ template <int W> struct Group
     float const prev = wave > 0 ? lds[slot * 16 + wave - 1] : fill;
     return lane_shift_up(x, prev);
   }
+  DCP_FN lf get_shift_keep(int slot, lf x, lf &) { return get_shift(slot, x, __builtin_inff()); }
   DCP_FN float get_min(int slot, lf)
   {
     float m = lds[slot * 16];
@@ -221,6 +244,64 @@ template <> DCP_FN void load_q<4>(float const *__restrict__ row, lu lane, lf (&o
   out[1] = v.y;
   out[2] = v.z;
   out[3] = v.w;
+}
+
+// ---- emission rows: { null, bg, 0, 0, match[0..Kp) } behind one scalar byte offset ----
+// Addressed through a buffer resource: the row offset travels in an SGPR (soffset) and
+// the lane's own offset in one VGPR computed once, so a row read costs no VALU at all.
+typedef unsigned int dcp_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int dcp_u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int dcp_u32x4 __attribute__((ext_vector_type(4)));
+
+struct RowSrc
+{
+  __amdgpu_buffer_rsrc_t rsrc;
+  char const *base;
+};
+
+DCP_FN RowSrc rowsrc_make(float const *__restrict__ base, uint32_t bytes)
+{
+  RowSrc r;
+  r.base = reinterpret_cast<char const *>(base);
+  r.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000);
+  return r;
+}
+
+// byte offset of a lane's Q positions inside a row
+template <int Q> DCP_FN lu row_lane_offset(lu lane) { return lane * (uint32_t)(Q * 4) + (uint32_t)(DCP_ROW_HDR * 4); }
+
+DCP_FN void load_row_hdr(RowSrc const &r, uint32_t soff, float &nil, float &bg)
+{
+  float2 const h = *reinterpret_cast<float2 const *>(r.base + soff); // uniform address: s_load_dwordx2
+  nil = h.x;
+  bg = h.y;
+}
+
+template <int Q> DCP_FN void load_row_q(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[Q]);
+template <> DCP_FN void load_row_q<1>(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[1])
+{
+  out[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r.rsrc, voff, soff, 0));
+}
+template <> DCP_FN void load_row_q<2>(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[2])
+{
+  dcp_u32x2 const v = __builtin_amdgcn_raw_buffer_load_b64(r.rsrc, voff, soff, 0);
+  out[0] = __uint_as_float(v.x);
+  out[1] = __uint_as_float(v.y);
+}
+template <> DCP_FN void load_row_q<3>(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[3])
+{
+  dcp_u32x3 const v = __builtin_amdgcn_raw_buffer_load_b96(r.rsrc, voff, soff, 0);
+  out[0] = __uint_as_float(v.x);
+  out[1] = __uint_as_float(v.y);
+  out[2] = __uint_as_float(v.z);
+}
+template <> DCP_FN void load_row_q<4>(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[4])
+{
+  dcp_u32x4 const v = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, voff, soff, 0);
+  out[0] = __uint_as_float(v.x);
+  out[1] = __uint_as_float(v.y);
+  out[2] = __uint_as_float(v.z);
+  out[3] = __uint_as_float(v.w);
 }
 
 // trellis node words of one row: positions k = lane*Q + q < K

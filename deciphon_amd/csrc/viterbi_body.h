@@ -23,15 +23,6 @@
 // ring slot of row l-t when row l has phase P = l % 5
 #define DCP_SL(P, t) (((P) + 5 - (t)) % 5)
 
-DCP_FN void dcp_unpack_codes(uint4 cr, unsigned (&c)[5])
-{
-  c[0] = cr.x & 0xffffu;
-  c[1] = cr.x >> 16;
-  c[2] = cr.y & 0xffffu;
-  c[3] = cr.y >> 16;
-  c[4] = cr.z & 0xffffu;
-}
-
 // =============================================================================
 // Scores only.  Only minima matter here, and fp32 min is exact and rounding is
 // monotone, so min_i((x_i + t_i) + m) == (min_i (x_i + t_i)) + m bit for bit.
@@ -56,38 +47,39 @@ template <int Q, int W> struct CostWave
   lf em[5][Q];
   lf sa, sb;
   lf X;
+  lf NBv, EBv, JBv;    // uniform, pinned to VGPRs
+  lf shM, shI, shD;    // destinations of the k-1 shifts; lane 0 stays +inf
   float nil[5], bgv[5];
-  float NB, EB, JB, ET, CT, RR;
+  float ET, CT, RR;
   float E;
-  float const *__restrict__ match;
-  float const *__restrict__ nullc;
-  float const *__restrict__ bgc;
-  uint4 const *__restrict__ codes;
-  int Kp;
+  RowSrc rows;
+  lu voff;
+  uint32_t stride_bytes;
+  DcpCodeRow const *__restrict__ codes;
 
+  // everything row l needs for its five emission lengths: one scalar offset each
   DCP_FN void prefetch(int l)
   {
-    unsigned c[5];
-    dcp_unpack_codes(codes[l], c);
+    DcpCodeRow const cr = codes[l];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
     {
-      nil[t] = nullc[c[t]];
-      bgv[t] = bgc[c[t]];
-      load_q<Q>(match + (size_t)c[t] * (size_t)Kp, g.lane, em[t]);
+      uint32_t const off = cr.c[t] * stride_bytes;
+      load_row_hdr(rows, off, nil[t], bgv[t]);
+      load_row_q<Q>(rows, voff, off, em[t]);
     }
   }
 
-  DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, uint4 const *__restrict__ code_rows,
+  DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, DcpCodeRow const *__restrict__ code_rows,
                    float const *__restrict__ xt)
   {
     g.init();
     lu const lane = g.lane;
-    match = pool + pf.match_off;
-    nullc = pool + pf.null_off;
-    bgc = pool + pf.bg_off;
+    int const Kp = pf.Kp;
+    stride_bytes = (uint32_t)(Kp + DCP_ROW_HDR) * 4u;
+    rows = rowsrc_make(pool + pf.rows_off, (uint32_t)DCP_TABLE_SIZE * stride_bytes);
+    voff = row_lane_offset<Q>(lane);
     codes = code_rows;
-    Kp = pf.Kp;
     float const *__restrict__ trans = pool + pf.trans_off;
     load_q<Q>(trans + DCP_BM * Kp, lane, BM);
     load_q<Q>(trans + DCP_MM * Kp, lane, MM);
@@ -97,9 +89,10 @@ template <int Q, int W> struct CostWave
     load_q<Q>(trans + DCP_II * Kp, lane, II);
     load_q<Q>(trans + DCP_DM * Kp, lane, DM);
     load_q<Q>(trans + DCP_DD * Kp, lane, DD);
-    NB = xt[DCP_NB];
-    EB = xt[DCP_EB];
-    JB = xt[DCP_JB];
+    NBv = lf_pin(xt[DCP_NB]);
+    EBv = lf_pin(xt[DCP_EB]);
+    JBv = lf_pin(xt[DCP_JB]);
+    shM = shI = shD = lf_splat(DCP_INF);
     ET = xt[DCP_ET];
     CT = xt[DCP_CT];
     RR = xt[DCP_RR];
@@ -158,12 +151,12 @@ template <int Q, int W> struct CostWave
     g.put_min(GS_E, m);
     g.put_lanes4(GS_X, X);
     g.sync();
-    lf const Msh0 = g.get_shift(GS_M, M[Q - 1], DCP_INF);
-    lf const Ish0 = g.get_shift(GS_I, I[Q - 1], DCP_INF);
+    lf const Msh0 = g.get_shift_keep(GS_M, M[Q - 1], shM);
+    lf const Ish0 = g.get_shift_keep(GS_I, I[Q - 1], shI);
     E = g.get_min(GS_E, m);
     float const N = g.get_lane(GS_X, X, 0);
     float const J = g.get_lane(GS_X, X, 1);
-    float const B = __builtin_fminf(__builtin_fminf(N + NB, E + EB), J + JB); // c-core/viterbi.c:495-496,582-583
+    lf const B = lmin3(N + NBv, E + EBv, J + JBv); // c-core/viterbi.c:495-496,582-583 (uniform)
 
     // D_l[k] = min(M_l[k-1] + MD[k], D_l[k-1] + DD[k])  (c-core/viterbi.c:538,553-580):
     // serial inside a lane, then carried across lanes until no lane improves (the
@@ -176,7 +169,7 @@ template <int Q, int W> struct CostWave
     {
       g.put_last(GS_D, D[Q - 1]);
       g.sync();
-      Dsh0 = g.get_shift(GS_D, D[Q - 1], DCP_INF);
+      Dsh0 = g.get_shift_keep(GS_D, D[Q - 1], shD);
       lf const x = Dsh0 + DD[0];
       lm const better = llt(x, D[0]);
       g.put_any(GS_F, better);
@@ -194,7 +187,7 @@ template <int Q, int W> struct CostWave
       lf const Ml = q ? M[q ? q - 1 : 0] : Msh0;
       lf const Il = q ? I[q ? q - 1 : 0] : Ish0;
       lf const Dl = q ? D[q ? q - 1 : 0] : Dsh0;
-      Mpre[P][q] = lmin3(lf_splat(B) + BM[q], Ml + MM[q], lmin(Il + IM[q], Dl + DM[q]));
+      Mpre[P][q] = lmin3(B + BM[q], Ml + MM[q], lmin(Il + IM[q], Dl + DM[q]));
       Ipre[P][q] = lmin(I[q] + II[q], M[q] + MI[q]);
     }
     Spre[P] = lmin(lf_splat(E) + sa, X + sb);
@@ -259,24 +252,24 @@ template <int Q, int W> struct PathWave
   lf M[5][Q], I[5][Q], D[5][Q], Msh[5], Ish[5], Dsh[5];
   float S[5], N[5], B[5], J[5], E[5], C[5];
   float xt[DCP_NUM_XTRANS];
-  int K, Kp;
-  float const *__restrict__ match;
-  float const *__restrict__ nullc;
-  float const *__restrict__ bgc;
-  uint4 const *__restrict__ codes;
+  int K;
+  RowSrc rows;
+  lu voff;
+  uint32_t stride_bytes;
+  DcpCodeRow const *__restrict__ codes;
   uint32_t *__restrict__ xnodes;
   uint16_t *__restrict__ nodes;
 
-  DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, uint4 const *__restrict__ code_rows,
+  DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, DcpCodeRow const *__restrict__ code_rows,
                    float const *__restrict__ xtp, uint32_t *__restrict__ xn, uint16_t *__restrict__ nd)
   {
     g.init();
     lu const lane = g.lane;
     K = pf.K;
-    Kp = pf.Kp;
-    match = pool + pf.match_off;
-    nullc = pool + pf.null_off;
-    bgc = pool + pf.bg_off;
+    int const Kp = pf.Kp;
+    stride_bytes = (uint32_t)(Kp + DCP_ROW_HDR) * 4u;
+    rows = rowsrc_make(pool + pf.rows_off, (uint32_t)DCP_TABLE_SIZE * stride_bytes);
+    voff = row_lane_offset<Q>(lane);
     codes = code_rows;
     xnodes = xn;
     nodes = nd;
@@ -398,10 +391,11 @@ template <int Q, int W> struct PathWave
   {
     (void)l;
     constexpr uint32_t u = (uint32_t)(T - 1);
-    float const nil = nullc[code];
-    float const bg = bgc[code];
+    uint32_t const off = code * stride_bytes;
+    float nil, bg;
+    load_row_hdr(rows, off, nil, bg);
     lf em[Q];
-    load_q<Q>(match + (size_t)code * (size_t)Kp, g.lane, em);
+    load_row_q<Q>(rows, voff, off, em);
 
     DCP_UPDS(Na, pN, (S[Z] + xt[DCP_SN]) + nil, 0u + u); // c-core/viterbi.c:492-493
     DCP_UPDS(Na, pN, (N[Z] + xt[DCP_NN]) + nil, 5u + u);
@@ -488,8 +482,8 @@ template <int Q, int W> struct PathWave
     }
     float Na = DCP_INF, Ba = DCP_INF, Ja = DCP_INF, Ea = DCP_INF, Ca = DCP_INF, Ta = DCP_INF;
     uint32_t pN = 0, pB = 0, pJ = 0, pE = 0, pC = 0, pT = 0; // prev_extr_state_init, :295-306
-    unsigned c[5];
-    dcp_unpack_codes(codes[l], c);
+    DcpCodeRow const cr = codes[l];
+    uint32_t const *c = cr.c;
 
     if (l >= 5) pass<5, DCP_SL(P, 5)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[4]);
     if (l >= 4) pass<4, DCP_SL(P, 4)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[3]);

@@ -11,7 +11,7 @@ template <int Q, int W>
 __global__ __launch_bounds__(64 * W) void dcp_cost_kernel(float const *__restrict__ pool,
                                                       DcpProfileDev const *__restrict__ profiles,
                                                       DcpProblem const *__restrict__ problems,
-                                                      uint4 const *__restrict__ code_rows,
+                                                      DcpCodeRow const *__restrict__ code_rows,
                                                       float const *__restrict__ xt_table,
                                                       float *__restrict__ out, int nprob)
 {
@@ -28,7 +28,7 @@ template <int Q, int W>
 __global__ __launch_bounds__(64 * W) void dcp_path_kernel(float const *__restrict__ pool,
                                                       DcpProfileDev const *__restrict__ profiles,
                                                       DcpProblem const *__restrict__ problems,
-                                                      uint4 const *__restrict__ code_rows,
+                                                      DcpCodeRow const *__restrict__ code_rows,
                                                       float const *__restrict__ xt_table,
                                                       unsigned char *__restrict__ arena,
                                                       float *__restrict__ out, int nprob)
@@ -69,7 +69,7 @@ __global__ void dcp_encode_kernel(unsigned char const *__restrict__ nt, int64_t 
       bool const ok = r - t >= 0;
       unsigned const sym = ok ? x[r - t] : 0u;
       idx += sym << (2 * (t - 1));
-      cr.c[t - 1] = ok ? (uint16_t)(off[t - 1] + idx) : (uint16_t)0;
+      cr.c[t - 1] = ok ? off[t - 1] + idx : 0u;
     }
     cr.c[5] = cr.c[6] = cr.c[7] = 0;
     out[r] = cr;
@@ -79,14 +79,14 @@ __global__ void dcp_encode_kernel(unsigned char const *__restrict__ nt, int64_t 
 template <int Q, int W> static hipError_t launch_cost_qw(DcpLaunch const &a)
 {
   hipLaunchKernelGGL((dcp_cost_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool, a.profiles,
-                     a.problems, reinterpret_cast<uint4 const *>(a.code_rows), a.xt_table, a.out, a.nprob);
+                     a.problems, a.code_rows, a.xt_table, a.out, a.nprob);
   return hipGetLastError();
 }
 
 template <int Q, int W> static hipError_t launch_path_qw(DcpLaunch const &a)
 {
   hipLaunchKernelGGL((dcp_path_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool, a.profiles,
-                     a.problems, reinterpret_cast<uint4 const *>(a.code_rows), a.xt_table, a.arena, a.out, a.nprob);
+                     a.problems, a.code_rows, a.xt_table, a.arena, a.out, a.nprob);
   return hipGetLastError();
 }
 

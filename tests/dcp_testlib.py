@@ -25,8 +25,10 @@ class ProfileDev(C.Structure):
     """struct DcpProfileDev (deciphon_amd/csrc/dcp_types.h)."""
 
     _fields_ = [("K", C.c_int32), ("Kp", C.c_int32), ("Q", C.c_int32), ("W", C.c_int32),
-                ("match_off", C.c_int64), ("trans_off", C.c_int64), ("null_off", C.c_int64),
-                ("bg_off", C.c_int64)]
+                ("rows_off", C.c_int64), ("trans_off", C.c_int64), ("pad0", C.c_int64), ("pad1", C.c_int64)]
+
+
+ROW_HDR = 4  # DCP_ROW_HDR: {null[c], bg[c], 0, 0} in front of every emission row
 
 
 def synth_profile(rng, K: int, quant=None, pinf: float = 0.0) -> Profile:
@@ -70,19 +72,22 @@ def pack_profile(prof: Profile, Q: int | None = None, W: int | None = None):
         Q, W = choose_qw(K)
     Kp = 64 * Q * W
     assert K <= Kp
-    match = np.full((TABLE_SIZE, Kp), INF, dtype=np.float32)
-    match[:, :K] = prof.match
+    rows = np.full((TABLE_SIZE, ROW_HDR + Kp), INF, dtype=np.float32)
+    rows[:, 0] = prof.null
+    rows[:, 1] = prof.bg
+    rows[:, 2:ROW_HDR] = 0
+    rows[:, ROW_HDR : ROW_HDR + K] = prof.match
     trans = np.full((8, Kp), INF, dtype=np.float32)
     trans[:, :K] = prof.trans
-    pool = np.concatenate([match.ravel(), trans.ravel(), prof.null, prof.bg]).astype(np.float32)
-    pd = ProfileDev(K, Kp, Q, W, 0, match.size, match.size + trans.size, match.size + trans.size + TABLE_SIZE)
+    pool = np.concatenate([rows.ravel(), trans.ravel()]).astype(np.float32)
+    pd = ProfileDev(K, Kp, Q, W, 0, rows.size, 0, 0)
     return pool, pd
 
 
 def code_rows(seq: np.ndarray) -> np.ndarray:
     """DcpCodeRow[len+1]: row r holds the codes of the t-mers covering r-t..r-1."""
     n = len(seq)
-    rows = np.zeros((n + 1, 8), dtype=np.uint16)
+    rows = np.zeros((n + 1, 8), dtype=np.uint32)
     s = seq.astype(np.int64)
     for t in range(1, 6):
         if n < t:

@@ -5,7 +5,7 @@
 #include "../../deciphon_amd/csrc/viterbi_body.h"
 
 template <int Q, int W>
-static void cost_q(float const *pool, DcpProfileDev const &pf, uint4 const *codes, int L, float const *xt, float *out)
+static void cost_q(float const *pool, DcpProfileDev const &pf, DcpCodeRow const *codes, int L, float const *xt, float *out)
 {
   static thread_local CostWave<Q, W> w; // 64*W-lane vectors are large: keep them off the stack
   w.init(pool, pf, codes, xt);
@@ -13,7 +13,7 @@ static void cost_q(float const *pool, DcpProfileDev const &pf, uint4 const *code
 }
 
 template <int Q, int W>
-static float path_q(float const *pool, DcpProfileDev const &pf, uint4 const *codes, int L, float const *xt,
+static float path_q(float const *pool, DcpProfileDev const &pf, DcpCodeRow const *codes, int L, float const *xt,
                     uint32_t *xnodes, uint16_t *nodes)
 {
   static thread_local PathWave<Q, W> w;
@@ -24,7 +24,7 @@ static float path_q(float const *pool, DcpProfileDev const &pf, uint4 const *cod
 extern "C" int emul_cost(float const *pool, DcpProfileDev const *pf, DcpCodeRow const *codes, int L, float const *xt,
                          float *out)
 {
-  uint4 const *c = reinterpret_cast<uint4 const *>(codes);
+  DcpCodeRow const *c = codes;
   switch (pf->Q * 100 + pf->W)
   {
   case 101: cost_q<1, 1>(pool, *pf, c, L, xt, out); return 0;
@@ -42,7 +42,7 @@ extern "C" int emul_cost(float const *pool, DcpProfileDev const *pf, DcpCodeRow 
 extern "C" int emul_path(float const *pool, DcpProfileDev const *pf, DcpCodeRow const *codes, int L, float const *xt,
                          uint32_t *xnodes, uint16_t *nodes, float *score)
 {
-  uint4 const *c = reinterpret_cast<uint4 const *>(codes);
+  DcpCodeRow const *c = codes;
   switch (pf->Q * 100 + pf->W)
   {
   case 101: *score = path_q<1, 1>(pool, *pf, c, L, xt, xnodes, nodes); return 0;

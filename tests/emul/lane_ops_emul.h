@@ -11,7 +11,6 @@
 #define DCP_FN inline
 #define DCP_WAVE 64
 
-struct uint4 { uint32_t x, y, z, w; };
 
 // A "group" of W wavefronts is emulated as ONE vector of 64*W lanes: values that the GPU
 // moves across wave boundaries through LDS simply shift / reduce across the whole vector.
@@ -59,6 +58,13 @@ inline lf lane_shift_up(lf x, float fill)
   return r;
 }
 
+inline lf lane_shift_up_keep(lf x, lf &keep)
+{
+  keep = lane_shift_up(x, keep.v[0]);
+  return keep;
+}
+inline lf lf_pin(float x) { return lf_splat(x); }
+
 inline float wave_min(lf v) { float m = v.v[0]; EM_FOR m = fminf(m, v.v[i_]); return m; }
 inline uint32_t wave_minu(lu v) { uint32_t m = v.v[0]; EM_FOR m = v.v[i_] < m ? v.v[i_] : m; return m; }
 inline bool wave_any(lm m) { EM_FOR if (m.v[i_]) return true; return false; }
@@ -84,6 +90,7 @@ template <int W> struct Group
   void put_count(int, lm) {}
   void sync() {}
   lf get_shift(int, lf x, float fill) { return lane_shift_up(x, fill); }
+  lf get_shift_keep(int, lf x, lf &keep) { return lane_shift_up_keep(x, keep); }
   float get_min(int, lf x) { return wave_min(x); }
   uint32_t get_minu(int, lu x) { return wave_minu(x); }
   float get_lane(int, lf x, int l) { return read_lane(x, l); }
@@ -94,6 +101,26 @@ template <int W> struct Group
 template <int Q> inline void load_q(float const *row, lu lane, lf (&out)[Q])
 {
   for (int q = 0; q < Q; ++q) EM_FOR out[q].v[i_] = row[lane.v[i_] * Q + q];
+}
+
+// emission rows { null, bg, 0, 0, match[0..Kp) } behind one byte offset (plain pointers here)
+struct RowSrc { char const *base; uint32_t bytes; };
+inline RowSrc rowsrc_make(float const *base, uint32_t bytes) { return RowSrc{reinterpret_cast<char const *>(base), bytes}; }
+template <int Q> inline lu row_lane_offset(lu lane) { return lane * (uint32_t)(Q * 4) + (uint32_t)16; }
+inline void load_row_hdr(RowSrc const &r, uint32_t soff, float &nil, float &bg)
+{
+  float const *h = reinterpret_cast<float const *>(r.base + soff);
+  nil = h[0];
+  bg = h[1];
+}
+template <int Q> inline void load_row_q(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[Q])
+{
+  for (int q = 0; q < Q; ++q)
+    EM_FOR
+    {
+      uint32_t const at = soff + voff.v[i_] + 4u * (uint32_t)q;
+      out[q].v[i_] = at + 4u <= r.bytes ? *reinterpret_cast<float const *>(r.base + at) : 0.0f; // buffer range check
+    }
 }
 
 template <int Q> inline void store_nodes_q(uint16_t *row, int K, lu lane, lu const (&w)[Q])
