@@ -264,7 +264,25 @@ int launch_all(dcp_hip *x, Staged const &st, bool path)
   return 0;
 }
 
-int launch_cost_all(dcp_hip *x, Staged const &st) { return launch_all(x, st, false); }
+// Cost pass.  A small launch that mixes single-wave classes goes out as ONE fused
+// kernel (classes 0..3 are contiguous in the sorted problem list); large launches keep
+// one kernel per class, which fills the GPU by itself and has its own register budget.
+int launch_cost_all(dcp_hip *x, Staged const &st)
+{
+  int const single_wave = st.c_begin[4] - st.c_begin[0];
+  int mixed = 0;
+  for (int c = 0; c < 4; ++c) mixed += st.c_begin[c + 1] > st.c_begin[c];
+  if (mixed < 2 || single_wave > 16384) return launch_all(x, st, false);
+  DcpLaunch a = launch_args(x, st, 0);
+  a.nprob = single_wave;
+  HIP_TRY(x, dcp_launch_cost_fused(a), DCP_EFUNCUSE);
+  for (int c = 4; c < DCP_NUM_CLASSES; ++c)
+  {
+    DcpLaunch b = launch_args(x, st, c);
+    HIP_TRY(x, dcp_launch_cost(c, b), DCP_EFUNCUSE);
+  }
+  return 0;
+}
 
 } // namespace
 

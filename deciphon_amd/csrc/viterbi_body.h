@@ -57,10 +57,14 @@ template <int Q, int W> struct CostWave
   uint32_t stride_bytes;
   DcpCodeRow const *__restrict__ codes;
 
-  // everything row l needs for its five emission lengths: one scalar offset each
-  DCP_FN void prefetch(int l)
+  DcpCodeRow cr; // codes of the next row to fetch, already resident in SGPRs
+
+  // Issues everything the row coded in `cr` needs for its five emission lengths (one
+  // scalar offset each), then pulls the codes of the row after it.  Codes run two rows
+  // ahead of the DP and emissions one, so neither the scalar nor the vector load
+  // latency sits on the row-to-row critical path.
+  DCP_FN void fetch(int l_after, int L)
   {
-    DcpCodeRow const cr = codes[l];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
     {
@@ -68,6 +72,7 @@ template <int Q, int W> struct CostWave
       load_row_hdr(rows, off, nil[t], bgv[t]);
       load_row_q<Q>(rows, voff, off, em[t]);
     }
+    cr = codes[l_after <= L ? l_after : L];
   }
 
   DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, DcpCodeRow const *__restrict__ code_rows,
@@ -140,7 +145,7 @@ template <int Q, int W> struct CostWave
               Spre[DCP_SL(P, 2)] + nil[1], Spre[DCP_SL(P, 1)] + nil[0]);
 
     // emissions of this row are consumed: fetch the next row's behind the rest
-    if (l < L) prefetch(l + 1);
+    if (l < L) fetch(l + 2, L);
 
     lf m = M[0];
 #pragma unroll
@@ -196,7 +201,11 @@ template <int Q, int W> struct CostWave
   // out[0] = viterbi_null(), out[1] = viterbi_cost()
   DCP_FN void run(int L, float *out)
   {
-    if (L > 0) prefetch(1);
+    if (L > 0)
+    {
+      cr = codes[1];
+      fetch(2, L);
+    }
     int l = 1;
     for (; l + 4 <= L; l += 5)
     {

@@ -25,5 +25,7 @@ struct DcpLaunch
 
 hipError_t dcp_launch_cost(int cls, DcpLaunch const &a);
 hipError_t dcp_launch_path(int cls, DcpLaunch const &a);
+// every problem of classes 0..3 (single-wave) in one launch
+hipError_t dcp_launch_cost_fused(DcpLaunch const &a);
 hipError_t dcp_launch_encode(unsigned char const *nt, int64_t const *seq_off, int64_t const *row_off, int nseq,
                              int64_t max_len, DcpCodeRow *rows, hipStream_t stream);

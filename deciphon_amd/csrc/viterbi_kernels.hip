@@ -24,6 +24,33 @@ __global__ __launch_bounds__(64 * W) void dcp_cost_kernel(float const *__restric
   w.run(pb.L, out + 2 * (size_t)pb.out);
 }
 
+// All single-wave classes in one launch: small scans (a few thousand windows spread
+// over several classes) would otherwise run their per-class kernels one after the
+// other, each too small to fill 1024 SIMDs.  Costs the register budget of the
+// largest class, so it is used only when the launch is small (engine.cpp).
+__global__ __launch_bounds__(64) void dcp_cost_kernel_fused(float const *__restrict__ pool,
+                                                            DcpProfileDev const *__restrict__ profiles,
+                                                            DcpProblem const *__restrict__ problems,
+                                                            DcpCodeRow const *__restrict__ code_rows,
+                                                            float const *__restrict__ xt_table,
+                                                            float *__restrict__ out, int nprob)
+{
+  int const p = (int)blockIdx.x;
+  if (p >= nprob) return;
+  DcpProblem const pb = problems[p];
+  DcpProfileDev const pf = profiles[pb.profile];
+  DcpCodeRow const *codes = code_rows + pb.code_row;
+  float const *xt = xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE;
+  float *o = out + 2 * (size_t)pb.out;
+  switch (pf.Q)
+  {
+  case 1: { CostWave<1, 1> w; w.init(pool, pf, codes, xt); w.run(pb.L, o); break; }
+  case 2: { CostWave<2, 1> w; w.init(pool, pf, codes, xt); w.run(pb.L, o); break; }
+  case 3: { CostWave<3, 1> w; w.init(pool, pf, codes, xt); w.run(pb.L, o); break; }
+  default: { CostWave<4, 1> w; w.init(pool, pf, codes, xt); w.run(pb.L, o); break; }
+  }
+}
+
 template <int Q, int W>
 __global__ __launch_bounds__(64 * W) void dcp_path_kernel(float const *__restrict__ pool,
                                                       DcpProfileDev const *__restrict__ profiles,
@@ -124,6 +151,14 @@ hipError_t dcp_launch_cost(int cls, DcpLaunch const &a)
   case 7: return launch_cost_qw<4, 16>(a);
   default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t dcp_launch_cost_fused(DcpLaunch const &a)
+{
+  if (a.nprob <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dcp_cost_kernel_fused, dim3((unsigned)a.nprob), dim3(64), 0, a.stream, a.pool, a.profiles,
+                     a.problems, a.code_rows, a.xt_table, a.out, a.nprob);
+  return hipGetLastError();
 }
 
 hipError_t dcp_launch_path(int cls, DcpLaunch const &a)

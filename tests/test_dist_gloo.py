@@ -40,13 +40,13 @@ WORKER = textwrap.dedent("""
     assert ddist.gather_rows(rows2, "cpu") == ["r0-0", "r1-0", "r1-1"]
     dist.barrier()
     dist.destroy_process_group()
-    print("rank", rank, "ok")
+    open(os.path.join({outdir!r}, "rank%d.ok" % rank), "w").write("ok")
 """)
 
 
 def test_two_ranks_gather_rows_in_rank_order(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(WORKER.format(root=ROOT, outdir=str(tmp_path)))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -55,4 +55,4 @@ def test_two_ranks_gather_rows_in_rank_order(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
