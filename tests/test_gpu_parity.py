@@ -228,3 +228,74 @@ def test_empty_and_invalid_calls(engine):
     with pytest.raises(deciphon_amd.HipError) as e:
         engine.cost([(0, 0, 0, 10 ** 7)])
     assert e.value.code == 8
+
+
+def test_full_size_config2_properties(engine, orc):
+    """BASELINE configs[1] at full size (minifam x 1000 synthetic 3 kb reads = the bench
+    workload): a random sample of windows against the oracle, bit-identical results across
+    two runs and across the staged (bench) entry points, and the planted domains are found."""
+    import bench
+    from oracle.dcp_reader import read_dcp
+
+    db = read_dcp(os.path.join(GOLDEN, "minifam.dcp"))
+    reads = bench.synth_reads(1000, 3000, [p.consensus for p in db.proteins])
+    engine.clear_profiles()
+    engine.load_dcp(os.path.join(GOLDEN, "minifam.dcp"))
+    engine.commit()
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    wins = [(p, s, 0, 3000) for p in range(3) for s in range(1000)]
+    nul, alt = engine.cost(wins)
+    nul2, alt2 = engine.cost(wins)
+    assert np.array_equal(nul.view(np.uint32), nul2.view(np.uint32))
+    assert np.array_equal(alt.view(np.uint32), alt2.view(np.uint32))
+    engine.stage(wins)
+    engine.run_staged(2)
+    nul3, alt3 = engine.fetch_staged()
+    assert np.array_equal(nul.view(np.uint32), nul3.view(np.uint32))
+    assert np.array_equal(alt.view(np.uint32), alt3.view(np.uint32))
+    # the null model does not depend on the profile (minifam shares one null table)
+    assert np.array_equal(nul[:1000].view(np.uint32), nul[1000:2000].view(np.uint32))
+    rng = np.random.default_rng(5)
+    profs = [orc.setup_profile(p) for p in db.proteins]
+    xt = orc.xtrans(1000, True, False)
+    for i in rng.choice(len(wins), size=24, replace=False):
+        p, s, _, _ = wins[i]
+        assert bits(nul[i]) == bits(orc.null(profs[p], xt, reads[s]))
+        assert bits(alt[i]) == bits(orc.cost(profs[p], xt, reads[s]))
+    lrt = -2.0 * ((-nul) - (-alt))
+    planted = [(s // 10 % 3, s) for s in range(0, 1000, 10)]  # bench.synth_reads: read s carries profile (s/10)%3
+    found = sum(lrt[p * 1000 + s] > 0 for p, s in planted)
+    assert found >= 90, found
+    others = np.ones(3000, bool)
+    for p, s in planted:
+        others[p * 1000 + s] = False
+    assert (lrt[others] > 0).mean() < 0.02
+
+
+def test_tiny_profile_many_windows_like_massive(engine, orc):
+    """BASELINE configs[2]: massive.hmm is a K = 3 profile (c-core/massive.hmm:2-5); a 10 kb
+    read gives 72 chained windows of 150 nt.  A synthetic K = 3 profile stands in (pressing
+    the HMM needs the absent imm library)."""
+    from deciphon_amd import host
+
+    rng = np.random.default_rng(8)
+    prof = synth_profile(rng, 3)
+    engine.clear_profiles()
+    engine.add_profile(3, prof.trans, prof.match, prof.null, prof.bg)
+    engine.commit()
+    reads = [random_seq(rng, 10000) for _ in range(20)] + [random_seq(rng, n) for n in range(1, 22)]
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    wins = []
+    for s, r in enumerate(reads):
+        it = host.WindowIter(len(r), 3)
+        while (w := it.next()) is not None:
+            wins.append((0, s, w[1], w[2]))
+    assert len(wins) > 20 * 70
+    nul, alt = engine.cost(wins)
+    for i in list(rng.choice(len(wins), size=200, replace=False)) + list(range(len(wins) - 21, len(wins))):
+        _, s, a, b = wins[i]
+        seq = np.ascontiguousarray(reads[s][a:b])
+        xt = orc.xtrans(max((b - a) // 3, 1), True, False)
+        assert bits(nul[i]) == bits(orc.null(prof, xt, seq)) and bits(alt[i]) == bits(orc.cost(prof, xt, seq))
