@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -68,7 +69,9 @@ struct PathResult
 {
   int K = 0, L = 0;
   float score = 0;
-  size_t arena_off = 0; // bytes into host_arena
+  size_t arena_off = 0;   // bytes into the device arena
+  size_t host_off = 0;    // bytes into host_arena once fetched
+  bool trellis_on_host = false;
   std::vector<int32_t> state_ids, seqsizes;
 };
 
@@ -109,7 +112,10 @@ struct dcp_hip
   DevBuf<DcpProblem> d_problems;
   DevBuf<float> d_out;
   DevBuf<unsigned char> d_arena;
-  std::vector<unsigned char> host_arena;
+  DevBuf<uint32_t> d_steps;
+  DevBuf<int64_t> d_step_off;
+  DevBuf<int32_t> d_nsteps;
+  std::vector<std::vector<unsigned char>> host_trellis; // fetched on demand, one per window
   std::vector<PathResult> paths;
   std::vector<DcpProblem> staged_problems; // dcp_hip_stage
   int staged_c_begin[DCP_NUM_CLASSES + 1] = {0};
@@ -289,6 +295,7 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
 extern "C" {
 
 void dcp_hip_del(struct dcp_hip *x);
+int dcp_hip_path_trellis(struct dcp_hip const *x, int i, uint32_t const **xnodes, uint16_t const **nodes);
 
 int dcp_hip_device_count(void)
 {
@@ -673,14 +680,46 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
   HIP_TRY(x, x->d_out.reserve((size_t)n), DCP_ENOMEM);
   HIP_TRY(x, x->d_arena.reserve(st.arena_bytes), DCP_ENOMEM);
   if ((rc = launch_all(x, st, true))) return rc;
-  x->host_arena.resize(st.arena_bytes);
-  std::vector<float> out((size_t)n);
-  HIP_TRY(x, hipMemcpyAsync(x->host_arena.data(), x->d_arena.p, st.arena_bytes, hipMemcpyDeviceToHost, x->stream),
+
+  // trellis_unzip on the device: only the paths (about L/3 steps of 4 bytes) cross PCIe,
+  // not the trellises ((L+1)*(2K+4) bytes each)
+  // A path has at most L emitting steps; mute steps (S, B, E, T, D runs) are few in
+  // practice.  Paths that do not fit are unzipped by the host from the fetched trellis.
+  // DECIPHON_HIP_UNZIP_CAP (steps) overrides the capacity: a test hook for that fallback.
+  int64_t cap_override = 0;
+  if (char const *e = getenv("DECIPHON_HIP_UNZIP_CAP")) cap_override = atoll(e);
+  std::vector<int64_t> step_off((size_t)n + 1, 0);
+  for (DcpProblem const &p : st.problems)
+    step_off[(size_t)p.out + 1] =
+        cap_override > 0 ? cap_override : 2 * (int64_t)p.L + 2 * (int64_t)x->profiles[(size_t)p.profile].K + 64;
+  for (int i = 0; i < n; ++i) step_off[(size_t)i + 1] += step_off[(size_t)i];
+  size_t const total_steps = (size_t)step_off[(size_t)n];
+  HIP_TRY(x, x->d_steps.reserve(total_steps), DCP_ENOMEM);
+  HIP_TRY(x, x->d_step_off.reserve((size_t)n + 1), DCP_ENOMEM);
+  HIP_TRY(x, x->d_nsteps.reserve((size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, hipMemcpyAsync(x->d_step_off.p, step_off.data(), ((size_t)n + 1) * sizeof(int64_t),
+                            hipMemcpyHostToDevice, x->stream),
           DCP_EFUNCUSE);
+  {
+    DcpLaunch a = launch_args(x, st, 0);
+    a.problems = x->d_problems.p;
+    a.nprob = n;
+    HIP_TRY(x, dcp_launch_unzip(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p), DCP_EFUNCUSE);
+  }
+  std::vector<float> out((size_t)n);
+  std::vector<int32_t> nsteps((size_t)n);
+  std::vector<uint32_t> steps(total_steps);
   HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipMemcpyAsync(nsteps.data(), x->d_nsteps.p, nsteps.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
+                            x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipMemcpyAsync(steps.data(), x->d_steps.p, total_steps * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                            x->stream),
           DCP_EFUNCUSE);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
   x->paths.resize((size_t)n);
+  x->host_trellis.assign((size_t)n, std::vector<unsigned char>());
   for (DcpProblem const &p : st.problems)
   {
     PathResult &r = x->paths[(size_t)p.out];
@@ -688,9 +727,27 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
     r.L = p.L;
     r.score = out[(size_t)p.out];
     r.arena_off = (size_t)p.trellis;
-    uint32_t const *xn = reinterpret_cast<uint32_t const *>(x->host_arena.data() + r.arena_off);
-    uint16_t const *nd = reinterpret_cast<uint16_t const *>(xn + (r.L + 1));
-    if ((rc = dcp_unzip(r.K, r.L, xn, nd, r.state_ids, r.seqsizes))) return fail(x, rc, "trellis_unzip failed");
+    r.trellis_on_host = false;
+    int32_t const ns = nsteps[(size_t)p.out];
+    if (ns >= 0)
+    {
+      uint32_t const *s = steps.data() + step_off[(size_t)p.out + 1] - ns;
+      r.state_ids.resize((size_t)ns);
+      r.seqsizes.resize((size_t)ns);
+      for (int32_t i = 0; i < ns; ++i)
+      {
+        r.state_ids[(size_t)i] = (int32_t)(s[i] & 0xffffu);
+        r.seqsizes[(size_t)i] = (int32_t)(s[i] >> 16);
+      }
+    }
+    else
+    {
+      // the device buffer was too small for this path: fetch the trellis and unzip here
+      uint32_t const *xn;
+      uint16_t const *nd;
+      if ((rc = dcp_hip_path_trellis(x, p.out, &xn, &nd))) return rc;
+      if ((rc = dcp_unzip(r.K, r.L, xn, nd, r.state_ids, r.seqsizes))) return fail(x, rc, "trellis_unzip failed");
+    }
   }
   return 0;
 }
@@ -710,11 +767,23 @@ int dcp_hip_path_steps(struct dcp_hip const *x, int i, int32_t *state_ids, int32
   return 0;
 }
 
-int dcp_hip_path_trellis(struct dcp_hip const *x, int i, uint32_t const **xnodes, uint16_t const **nodes)
+int dcp_hip_path_trellis(struct dcp_hip const *cx, int i, uint32_t const **xnodes, uint16_t const **nodes)
 {
+  dcp_hip *x = const_cast<dcp_hip *>(cx);
   if (!x || i < 0 || i >= (int)x->paths.size() || !xnodes || !nodes) return DCP_EFUNCUSE;
-  PathResult const &r = x->paths[(size_t)i];
-  uint32_t const *xn = reinterpret_cast<uint32_t const *>(x->host_arena.data() + r.arena_off);
+  PathResult &r = x->paths[(size_t)i];
+  std::vector<unsigned char> &buf = x->host_trellis[(size_t)i];
+  if (!r.trellis_on_host) // trellises stay in HBM until somebody asks for one
+  {
+    size_t const bytes = ((size_t)r.L + 1) * 4 + ((size_t)r.L + 1) * (size_t)r.K * 2;
+    buf.resize(bytes);
+    HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+    HIP_TRY(x, hipMemcpyAsync(buf.data(), x->d_arena.p + r.arena_off, bytes, hipMemcpyDeviceToHost, x->stream),
+            DCP_EFUNCUSE);
+    HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+    r.trellis_on_host = true;
+  }
+  uint32_t const *xn = reinterpret_cast<uint32_t const *>(buf.data());
   *xnodes = xn;
   *nodes = reinterpret_cast<uint16_t const *>(xn + (r.L + 1));
   return 0;

@@ -103,6 +103,101 @@ __global__ void dcp_encode_kernel(unsigned char const *__restrict__ nt, int64_t 
   }
 }
 
+// trellis_unzip on the device (c-core/trellis.c:147-167 with previous_state and
+// emission_size, :51-113): one thread walks one problem's trellis from T at stage L
+// back to S at stage 0 and writes the steps, packed as state_id | seqsize << 16, from
+// the END of its buffer backwards, so that they read forwards in path order.
+// nsteps[p] = number of steps, or -1 when the buffer was too small / the trellis is
+// inconsistent (the host then unzips that one itself).
+__global__ void dcp_unzip_kernel(DcpProfileDev const *__restrict__ profiles, DcpProblem const *__restrict__ problems,
+                                 unsigned char const *__restrict__ arena, uint32_t *__restrict__ steps,
+                                 int64_t const *__restrict__ step_off, int32_t *__restrict__ nsteps, int nprob)
+{
+  int const p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (p >= nprob) return;
+  DcpProblem const pb = problems[p];
+  int const K = profiles[pb.profile].K;
+  int const L = pb.L;
+  uint32_t const *xnodes = reinterpret_cast<uint32_t const *>(arena + pb.trellis);
+  uint16_t const *nodes = reinterpret_cast<uint16_t const *>(xnodes + (L + 1));
+  uint32_t *buf = steps + step_off[pb.out];
+  int64_t const cap = step_off[pb.out + 1] - step_off[pb.out];
+  enum
+  {
+    ST_M = 0 << 14, ST_I = 1 << 14, ST_D = 2 << 14, ST_X = 3 << 14, // c-core/state.h:9-25
+    ST_S = ST_X | 3, ST_N = ST_X | 4, ST_B = ST_X | 5, ST_E = ST_X | 6, ST_J = ST_X | 7, ST_C = ST_X | 8, ST_T = ST_X | 9,
+  };
+  int state = ST_T, stage = L;
+  int64_t n = 0;
+  bool bad = false;
+  while ((state != ST_S || stage) && !bad)
+  {
+    int size = 0, prev = 0;
+    if ((state & ST_X) == ST_X)
+    {
+      uint32_t const x = xnodes[stage];
+      if (state == ST_N) { unsigned v = x & 0xF; size = (int)(v % 5) + 1; prev = v / 5 ? ST_N : ST_S; }
+      else if (state == ST_B) { unsigned v = (x >> 4) & 0x3; prev = v == 0 ? ST_S : v == 1 ? ST_N : v == 2 ? ST_E : ST_J; }
+      else if (state == ST_E) { unsigned v = (x >> 6) & 0x7FFF; prev = (v & 1 ? ST_D : ST_M) | (int)(v / 2 + 1); }
+      else if (state == ST_C) { unsigned v = (x >> 21) & 0xF; size = (int)(v % 5) + 1; prev = v / 5 ? ST_C : ST_E; }
+      else if (state == ST_T) { unsigned v = (x >> 25) & 0x1; prev = v ? ST_C : ST_E; }
+      else if (state == ST_J) { unsigned v = (x >> 26) & 0xF; size = (int)(v % 5) + 1; prev = v / 5 ? ST_J : ST_E; }
+      else bad = true;
+    }
+    else
+    {
+      int const idx = (state & 0x3FFF) - 1;
+      if (idx < 0 || idx >= K) { bad = true; break; }
+      uint16_t const w = nodes[(size_t)stage * (size_t)K + (size_t)idx];
+      int const kind = state & ST_X;
+      if (kind == ST_M)
+      {
+        unsigned v = w & 0x1F;
+        size = (int)(v % 5) + 1;
+        unsigned s = v / 5;
+        if (s == 0) prev = ST_B;
+        else if (idx <= 0) bad = true;
+        else prev = (s == 1 ? ST_M : s == 2 ? ST_I : ST_D) | idx;
+      }
+      else if (kind == ST_D)
+      {
+        unsigned v = (w >> 5) & 0x1;
+        if (idx <= 0) bad = true;
+        else prev = (v ? ST_D : ST_M) | idx;
+      }
+      else
+      {
+        unsigned v = (w >> 6) & 0xF;
+        size = (int)(v % 5) + 1;
+        prev = (v / 5 ? ST_I : ST_M) | (idx + 1);
+      }
+    }
+    if (bad || n + 1 >= cap) { bad = true; break; }
+    buf[cap - 1 - n] = (uint32_t)state | ((uint32_t)size << 16);
+    ++n;
+    state = prev;
+    stage -= size;
+    if (stage < 0) bad = true;
+  }
+  if (!bad && n < cap)
+  {
+    buf[cap - 1 - n] = (uint32_t)state; // the start state, no emission
+    ++n;
+  }
+  else
+    bad = true;
+  nsteps[pb.out] = bad ? -1 : (int32_t)n;
+}
+
+hipError_t dcp_launch_unzip(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps)
+{
+  if (a.nprob <= 0) return hipSuccess;
+  unsigned const blocks = (unsigned)((a.nprob + 63) / 64);
+  hipLaunchKernelGGL(dcp_unzip_kernel, dim3(blocks), dim3(64), 0, a.stream, a.profiles, a.problems, a.arena, steps,
+                     step_off, nsteps, a.nprob);
+  return hipGetLastError();
+}
+
 template <int Q, int W> static hipError_t launch_cost_qw(DcpLaunch const &a)
 {
   hipLaunchKernelGGL((dcp_cost_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool, a.profiles,

@@ -299,3 +299,33 @@ def test_tiny_profile_many_windows_like_massive(engine, orc):
         seq = np.ascontiguousarray(reads[s][a:b])
         xt = orc.xtrans(max((b - a) // 3, 1), True, False)
         assert bits(nul[i]) == bits(orc.null(prof, xt, seq)) and bits(alt[i]) == bits(orc.cost(prof, xt, seq))
+
+
+def test_device_unzip_and_host_fallback(engine, orc, monkeypatch):
+    """trellis_unzip runs on the GPU; a path that does not fit its step buffer falls back to
+    the host unzip of the fetched trellis.  Both must give the reference's steps."""
+    import deciphon_amd
+
+    engine.clear_profiles()
+    engine.load_dcp(os.path.join(GOLDEN, "minifam.dcp"))
+    engine.commit()
+    reads = [deciphon_amd.encode(s) for _, s in _reads()]
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    wins = [(0, 0, 0, len(reads[0])), (1, 1, 0, len(reads[1])), (0, 3, 0, len(reads[3])), (2, 2, 10, 400)]
+    normal = engine.path(wins)
+    monkeypatch.setenv("DECIPHON_HIP_UNZIP_CAP", "50")  # far too small: every path overflows
+    fallback = engine.path(wins)
+    monkeypatch.delenv("DECIPHON_HIP_UNZIP_CAP")
+    from oracle.dcp_reader import read_dcp
+
+    db = read_dcp(os.path.join(GOLDEN, "minifam.dcp"))
+    for (p, s, a, b), x, y in zip(wins, normal, fallback):
+        prof = orc.setup_profile(db.proteins[p])
+        seq = np.ascontiguousarray(reads[s][a:b])
+        xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+        _, xo, no = orc.path(prof, xt, seq)
+        ids, sizes = orc.unzip(prof.K, len(seq), xo, no)
+        for r in (x, y):
+            assert np.array_equal(r["state_ids"], ids) and np.array_equal(r["seqsizes"], sizes)
+            assert np.array_equal(r["xnodes"], xo) and np.array_equal(r["nodes"], no)
