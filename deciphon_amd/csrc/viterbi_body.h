@@ -266,6 +266,9 @@ template <int Q, int W> struct PathWave
   lu voff;
   uint32_t stride_bytes;
   DcpCodeRow const *__restrict__ codes;
+  DcpCodeRow cr;          // codes of the next row to fetch
+  lf em[5][Q];            // emissions of the row being computed, one set per emission length
+  float nil[5], bgv[5];
   uint32_t *__restrict__ xnodes;
   uint16_t *__restrict__ nodes;
 
@@ -396,15 +399,13 @@ template <int Q, int W> struct PathWave
   template <int T, int Z>
   DCP_FN void pass(int l, lf (&Ma)[Q], lf (&Ia)[Q], lf (&Da)[Q], lu (&pM)[Q], lu (&pI)[Q], lu (&pD)[Q], float &Na,
                    float &Ba, float &Ja, float &Ea, float &Ca, float &Ta, uint32_t &pN, uint32_t &pB, uint32_t &pJ,
-                   uint32_t &pE, uint32_t &pC, uint32_t &pT, unsigned code)
+                   uint32_t &pE, uint32_t &pC, uint32_t &pT)
   {
     (void)l;
     constexpr uint32_t u = (uint32_t)(T - 1);
-    uint32_t const off = code * stride_bytes;
-    float nil, bg;
-    load_row_hdr(rows, off, nil, bg);
-    lf em[Q];
-    load_row_q<Q>(rows, voff, off, em);
+    float const nil = this->nil[T - 1];
+    float const bg = this->bgv[T - 1];
+    lf const(&em)[Q] = this->em[T - 1];
 
     DCP_UPDS(Na, pN, (S[Z] + xt[DCP_SN]) + nil, 0u + u); // c-core/viterbi.c:492-493
     DCP_UPDS(Na, pN, (N[Z] + xt[DCP_NN]) + nil, 5u + u);
@@ -478,7 +479,20 @@ template <int Q, int W> struct PathWave
     DCP_UPDS(Ta, pT, Ca + xt[DCP_CT], 1u);
   }
 
-  template <int P> DCP_FN float row(int l)
+  // as CostWave::fetch: emissions run one row ahead of the DP, codes two
+  DCP_FN void fetch(int l_after, int L)
+  {
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+    {
+      uint32_t const off = cr.c[t] * stride_bytes;
+      load_row_hdr(rows, off, nil[t], bgv[t]);
+      load_row_q<Q>(rows, voff, off, em[t]);
+    }
+    cr = codes[l_after <= L ? l_after : L];
+  }
+
+  template <int P> DCP_FN float row(int l, int L)
   {
     lf const inf = lf_splat(DCP_INF);
     lf Ma[Q], Ia[Q], Da[Q];
@@ -491,14 +505,14 @@ template <int Q, int W> struct PathWave
     }
     float Na = DCP_INF, Ba = DCP_INF, Ja = DCP_INF, Ea = DCP_INF, Ca = DCP_INF, Ta = DCP_INF;
     uint32_t pN = 0, pB = 0, pJ = 0, pE = 0, pC = 0, pT = 0; // prev_extr_state_init, :295-306
-    DcpCodeRow const cr = codes[l];
-    uint32_t const *c = cr.c;
 
-    if (l >= 5) pass<5, DCP_SL(P, 5)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[4]);
-    if (l >= 4) pass<4, DCP_SL(P, 4)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[3]);
-    if (l >= 3) pass<3, DCP_SL(P, 3)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[2]);
-    if (l >= 2) pass<2, DCP_SL(P, 2)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[1]);
-    pass<1, DCP_SL(P, 1)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT, c[0]);
+    if (l >= 5) pass<5, DCP_SL(P, 5)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT);
+    if (l >= 4) pass<4, DCP_SL(P, 4)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT);
+    if (l >= 3) pass<3, DCP_SL(P, 3)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT);
+    if (l >= 2) pass<2, DCP_SL(P, 2)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT);
+    pass<1, DCP_SL(P, 1)>(l, Ma, Ia, Da, pM, pI, pD, Na, Ba, Ja, Ea, Ca, Ta, pN, pB, pJ, pE, pC, pT);
+    // this row's emissions are consumed: fetch the next row's while the pointers are packed
+    if (l < L) fetch(l + 2, L);
 
     // after(): pack the row's pointers (c-core/viterbi.c:631-694)
     lu const lane = g.lane;
@@ -543,19 +557,24 @@ template <int Q, int W> struct PathWave
   DCP_FN float run(int L)
   {
     float T = DCP_INF;
+    if (L > 0)
+    {
+      cr = codes[1];
+      fetch(2, L);
+    }
     int l = 1;
     for (; l + 4 <= L; l += 5)
     {
-      T = row<1>(l);
-      T = row<2>(l + 1);
-      T = row<3>(l + 2);
-      T = row<4>(l + 3);
-      T = row<0>(l + 4);
+      T = row<1>(l, L);
+      T = row<2>(l + 1, L);
+      T = row<3>(l + 2, L);
+      T = row<4>(l + 3, L);
+      T = row<0>(l + 4, L);
     }
-    if (l <= L) T = row<1>(l++);
-    if (l <= L) T = row<2>(l++);
-    if (l <= L) T = row<3>(l++);
-    if (l <= L) T = row<4>(l++);
+    if (l <= L) T = row<1>(l++, L);
+    if (l <= L) T = row<2>(l++, L);
+    if (l <= L) T = row<3>(l++, L);
+    if (l <= L) T = row<4>(l++, L);
     return T;
   }
 };
