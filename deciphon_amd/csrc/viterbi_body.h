@@ -169,20 +169,25 @@ template <int Q, int W> struct CostWave
     D[0] = Msh0 + MD[0];
 #pragma unroll
     for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
-    lf Dsh0;
-    for (;;)
+    g.put_last(GS_D, D[Q - 1]);
+    g.sync();
+    lf Dsh0 = g.get_shift_keep(GS_D, D[Q - 1], shD);
+    lf x = Dsh0 + DD[0];
+    lm better = llt(x, D[0]);
+    g.put_any(GS_F, better);
+    g.sync();
+    while (g.get_any(GS_F, better)) // one more lane boundary per turn; a few turns per row on real data
     {
-      g.put_last(GS_D, D[Q - 1]);
-      g.sync();
-      Dsh0 = g.get_shift_keep(GS_D, D[Q - 1], shD);
-      lf const x = Dsh0 + DD[0];
-      lm const better = llt(x, D[0]);
-      g.put_any(GS_F, better);
-      g.sync();
-      if (!g.get_any(GS_F, better)) break;
       D[0] = lmin(D[0], x);
 #pragma unroll
       for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+      g.put_last(GS_D, D[Q - 1]);
+      g.sync();
+      Dsh0 = g.get_shift_keep(GS_D, D[Q - 1], shD);
+      x = Dsh0 + DD[0];
+      better = llt(x, D[0]);
+      g.put_any(GS_F, better);
+      g.sync();
     }
 
     // fold row l into the ring (slot P held row l-5, no longer needed)
