@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <errno.h>
 #include <math.h>
 #include <stdio.h>
@@ -91,6 +92,20 @@ int mkdir_p(std::string const &dir)
   return DCP_EMKDIR;
 }
 
+// DECIPHON_HIP_TIMING=1: phase times of dcp_scan_run on stderr
+struct Phase
+{
+  double windows = 0, cost = 0, path = 0, rows = 0, write = 0;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  double lap()
+  {
+    auto n = std::chrono::steady_clock::now();
+    double d = std::chrono::duration<double>(n - t).count();
+    t = n;
+    return d;
+  }
+};
+
 struct Pair
 {
   int profile, seq;
@@ -114,6 +129,7 @@ std::string format_row(dcp_batch::Seq const &seq, int window, int wstart, int ws
   snprintf(head, sizeof head, "%ld\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%s\t%.1f\tnan\t", seq.id, window, wstart, wstop, 0,
            hit.hit_start, hit.hit_stop, accession, abc, (double)lrt);
   std::string out = head;
+  out.reserve(out.size() + (size_t)(hit.end_step - hit.begin_step) * 12);
   int pos = 0;
   for (int i = 0; i < hit.begin_step; ++i) pos += sizes[(size_t)i];
   for (int i = hit.begin_step; i < hit.end_step; ++i)
@@ -235,6 +251,9 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   if ((rc = mkdir_p(dir))) return raise(rc, __func__, product_dir);
 
   std::vector<Row> rows;
+  Phase ph;
+  int rounds = 0;
+  size_t nwindows = 0, nhits = 0;
   int const nprof = dcp_hip_num_profiles(x->eng);
   // profiles are walked in chunks so that the pair table stays small
   size_t const max_pairs = 1u << 21;
@@ -264,9 +283,13 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
         owner.push_back(i);
       }
       if (wins.empty()) break;
+      ++rounds;
+      nwindows += wins.size();
+      ph.windows += ph.lap();
       std::vector<float> nul(wins.size()), alt(wins.size());
       if ((rc = dcp_hip_cost(x->eng, (int)wins.size(), wins.data(), nul.data(), alt.data())))
         return raise(rc, __func__, dcp_hip_strerror(x->eng));
+      ph.cost += ph.lap();
 
       // c-core/thread.c:114-121
       std::vector<dcp_hip_window> hits;
@@ -294,8 +317,11 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
           bytes += b;
           ++h1;
         }
+        nhits += h1 - h0;
+        ph.windows += ph.lap();
         if ((rc = dcp_hip_path(x->eng, (int)(h1 - h0), hits.data() + h0)))
           return raise(rc, __func__, dcp_hip_strerror(x->eng));
+        ph.path += ph.lap();
         for (size_t h = h0; h < h1; ++h)
         {
           int const n = dcp_hip_path_nsteps(x->eng, (int)(h - h0));
@@ -312,6 +338,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
                                         lrts[h], ids, sizes)});
         }
         h0 = h1;
+        ph.rows += ph.lap();
       }
       if (x->callback)
         for (size_t i = 0; i < wins.size(); ++i) x->callback(x->userdata); // once per window, c-core/thread.c:74
@@ -337,6 +364,12 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     x->products.push_back(r.text);
   }
   if (fclose(fp) != 0 || !ok) return raise(DCP_EWRITEPROD, __func__, file.c_str());
+  ph.write += ph.lap();
+  if (getenv("DECIPHON_HIP_TIMING"))
+    fprintf(stderr,
+            "dcp_scan_run: %d rounds, %zu windows, %zu path passes; windows %.3f s, cost pass %.3f s, path pass %.3f s, "
+            "rows %.3f s, products.tsv %.3f s\n",
+            rounds, nwindows, nhits, ph.windows, ph.cost, ph.path, ph.rows, ph.write);
   return 0;
 }
 
