@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Cost-pass throughput per kernel class: one synthetic profile of a given K against enough
+reads to fill the GPU (throughput mode)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import deciphon_amd
+from dcp_testlib import random_seq, synth_profile
+
+rng = np.random.default_rng(3)
+eng = deciphon_amd.Engine(0)
+L = 1000
+reads = [random_seq(rng, L) for _ in range(16384)]
+eng.set_sequences(reads)
+eng.set_mode(True, False)
+for K in [int(a) for a in (sys.argv[1:] or "3 16 32 64 100 128 173 192 241 256 400 512 900 1024 1800 2048 4096".split())]:
+    eng.clear_profiles()
+    p = synth_profile(rng, K)
+    eng.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    eng.commit()
+    nreads = int(min(len(reads), max(512, 3.0e9 / (K * L))))
+    wins = [(0, s, 0, L) for s in range(nreads)]
+    eng.stage(wins)
+    eng.run_staged(1)
+    ms, cells = eng.run_staged(3)
+    print(f"K={K:5d}  windows={nreads:6d}  {ms / 3:8.2f} ms  {cells / (ms / 3 * 1e-3) / 1e9:7.1f} GCUPS")
