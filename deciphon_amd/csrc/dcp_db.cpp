@@ -357,6 +357,22 @@ int DcpDbReader::read_protein(int i, DcpProtein &x) const
   return 0;
 }
 
+int DcpDbReader::read_protein_head(int i, int &core_size, std::string &accession) const
+{
+  if (!data_ || i < 0 || i >= num_proteins()) return DCP_EINVALPART;
+  Cur c{data_ + offsets_[(size_t)i], data_ + offsets_[(size_t)i + 1]};
+  int64_t v = 0;
+  std::string consensus;
+  if (!expect_map(c, 10)) return DCP_EFDATA;
+  if (!expect_key(c, "accession") || !read_str(c, accession, 32)) return DCP_EFDATA;
+  if (!expect_key(c, "gencode") || !read_int(c, v)) return DCP_EFDATA;
+  if (!expect_key(c, "consensus") || !read_str(c, consensus, DCP_MODEL_MAX + 1)) return DCP_EFDATA;
+  if (!expect_key(c, "core_size") || !read_int(c, v)) return DCP_EFDATA;
+  if (v <= 0 || v > DCP_MODEL_MAX) return DCP_ELARGECORESIZE;
+  core_size = (int)v;
+  return 0;
+}
+
 long dcp_partition_size(long nelems, long nparts, long idx)
 {
   long x = nelems - idx;

@@ -56,6 +56,8 @@ public:
   // byte offset of protein i inside the file (protein_reader's partition offsets)
   int64_t protein_offset(int i) const { return offsets_[(size_t)i]; }
   int read_protein(int i, DcpProtein &out) const;
+  // only accession and core size (the first keys of the record): cheap pre-scan
+  int read_protein_head(int i, int &core_size, std::string &accession) const;
 
 private:
   uint8_t const *data_ = nullptr;

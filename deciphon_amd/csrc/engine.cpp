@@ -21,11 +21,13 @@
 #include "viterbi_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace
@@ -88,11 +90,10 @@ struct dcp_hip
   std::string err;
 
   // profiles
-  std::vector<float> pool; // host staging
   std::vector<HostProfile> profiles;
-  size_t committed = 0; // profiles already in HBM
-  size_t committed_floats = 0;
+  size_t committed = 0; // profiles whose descriptors are published
   DevBuf<float> d_pool;
+  size_t pool_used = 0; // floats of d_pool holding profiles
   DevBuf<DcpProfileDev> d_profiles;
 
   // sequences
@@ -345,26 +346,56 @@ void dcp_hip_del(struct dcp_hip *x)
 
 char const *dcp_hip_strerror(struct dcp_hip const *x) { return x ? x->err.c_str() : "no engine"; }
 
-static int add_slot(dcp_hip *x, int K, char const *accession, float **trans, float **rows, int *index)
+// ---- profiles: HBM is the only resident copy ---------------------------------------
+// A profile is laid out on the host in a staging buffer (rows | trans, +inf padded) and
+// copied behind the profiles already resident; nothing Pfam-sized is ever held twice.
+
+static size_t profile_floats(int Kp)
+{
+  size_t const floats = (size_t)DCP_TABLE_SIZE * ((size_t)Kp + DCP_ROW_HDR) + (size_t)DCP_NUM_TRANS * (size_t)Kp;
+  return (floats + 3) & ~(size_t)3; // keep every profile 16-byte aligned for the dwordx4 row loads
+}
+
+static int describe(dcp_hip *x, int K, char const *accession, HostProfile &hp)
 {
   if (K < 1 || K > DCP_MODEL_MAX) return fail(x, DCP_ELARGECORESIZE, "core size out of range");
   int const cls = dcp_class_of(K);
   if (cls < 0) return fail(x, DCP_ELARGECORESIZE, "core size beyond DCP_MAX_CORE_SIZE (4096) is not supported yet");
-  HostProfile hp;
   hp.K = K;
   hp.cls = cls;
   dcp_class_shape(cls, &hp.Q, &hp.W);
   hp.Kp = 64 * hp.Q * hp.W;
-  hp.pool_off = (int64_t)x->pool.size();
+  hp.pool_off = 0;
   hp.accession = accession ? accession : "";
-  size_t const stride = (size_t)hp.Kp + DCP_ROW_HDR;
-  size_t const floats = (size_t)DCP_TABLE_SIZE * stride + (size_t)DCP_NUM_TRANS * hp.Kp;
-  // keep every profile 16-byte aligned for the dwordx4 row loads
-  size_t const padded = (floats + 3) & ~(size_t)3;
-  x->pool.resize(x->pool.size() + padded, INFINITY);
-  float *base = x->pool.data() + hp.pool_off;
-  *rows = base;
-  *trans = base + (size_t)DCP_TABLE_SIZE * stride;
+  return 0;
+}
+
+// grows the device pool to `floats`, keeping what is resident
+static int ensure_pool(dcp_hip *x, size_t floats)
+{
+  if (floats <= x->d_pool.cap) return 0;
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  DevBuf<float> bigger;
+  HIP_TRY(x, bigger.reserve(std::max(floats, x->d_pool.cap + x->d_pool.cap / 2)), DCP_ENOMEM);
+  if (x->pool_used)
+    HIP_TRY(x, hipMemcpy(bigger.p, x->d_pool.p, x->pool_used * sizeof(float), hipMemcpyDeviceToDevice), DCP_EFUNCUSE);
+  x->d_pool.release();
+  x->d_pool.p = bigger.p;
+  x->d_pool.cap = bigger.cap;
+  bigger.p = nullptr;
+  bigger.cap = 0;
+  return 0;
+}
+
+// one profile from a host staging buffer to the end of the pool
+static int push_profile(dcp_hip *x, HostProfile hp, std::vector<float> const &staged, int *index)
+{
+  int rc = ensure_pool(x, x->pool_used + staged.size());
+  if (rc) return rc;
+  hp.pool_off = (int64_t)x->pool_used;
+  HIP_TRY(x, hipMemcpy(x->d_pool.p + x->pool_used, staged.data(), staged.size() * sizeof(float), hipMemcpyHostToDevice),
+          DCP_EFUNCUSE);
+  x->pool_used += staged.size();
   if (index) *index = (int)x->profiles.size();
   x->profiles.push_back(hp);
   return 0;
@@ -374,11 +405,15 @@ int dcp_hip_add_profile(struct dcp_hip *x, int K, float const *trans, float cons
                         float const *bg_cost, int *index)
 {
   if (!x || !trans || !match || !null_cost || !bg_cost) return DCP_EFUNCUSE;
-  float *t, *r;
-  int rc = add_slot(x, K, nullptr, &t, &r, index);
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  HostProfile hp;
+  int rc = describe(x, K, nullptr, hp);
   if (rc) return rc;
-  int const Kp = x->profiles.back().Kp;
+  int const Kp = hp.Kp;
   size_t const stride = (size_t)Kp + DCP_ROW_HDR;
+  std::vector<float> buf(profile_floats(Kp), INFINITY);
+  float *r = buf.data();
+  float *t = r + (size_t)DCP_TABLE_SIZE * stride;
   for (int id = 0; id < DCP_NUM_TRANS; ++id) memcpy(t + (size_t)id * Kp, trans + (size_t)id * K, sizeof(float) * K);
   for (int c = 0; c < DCP_TABLE_SIZE; ++c)
   {
@@ -388,38 +423,136 @@ int dcp_hip_add_profile(struct dcp_hip *x, int K, float const *trans, float cons
     hdr[2] = hdr[3] = 0.0f;
     memcpy(hdr + DCP_ROW_HDR, match + (size_t)c * K, sizeof(float) * K);
   }
-  return 0;
+  return push_profile(x, hp, buf, index);
 }
 
 int dcp_hip_add_protein(struct dcp_hip *x, int K, float const *node_trans, float const *node_emission,
                         float const *BMk, float const *null_lprob, float const *bg_lprob, int *index)
 {
   if (!x || !node_trans || !node_emission || !BMk || !null_lprob || !bg_lprob) return DCP_EFUNCUSE;
-  float *t, *r;
-  int rc = add_slot(x, K, nullptr, &t, &r, index);
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  HostProfile hp;
+  int rc = describe(x, K, nullptr, hp);
   if (rc) return rc;
-  dcp_setup_profile(K, x->profiles.back().Kp, node_trans, node_emission, BMk, null_lprob, bg_lprob, t, r);
-  return 0;
+  std::vector<float> buf(profile_floats(hp.Kp), INFINITY);
+  float *r = buf.data();
+  float *t = r + (size_t)DCP_TABLE_SIZE * ((size_t)hp.Kp + DCP_ROW_HDR);
+  dcp_setup_profile(K, hp.Kp, node_trans, node_emission, BMk, null_lprob, bg_lprob, t, r);
+  return push_profile(x, hp, buf, index);
 }
 
+// Streams proteins [first, first+count) of a pressed database into HBM: core sizes are read
+// first (so the pool is sized once), then the proteins are unpacked and transposed into
+// code-major rows by up to 16 host threads, chunk by chunk, into two pinned staging buffers whose
+// H2D copies overlap the unpacking of the next chunk.
 int dcp_hip_load_dcp(struct dcp_hip *x, char const *path, int first, int count)
 {
   if (!x || !path) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   DcpDbReader db;
   int rc = db.open(path);
   if (rc) return fail(x, rc, "cannot open database");
   int const N = db.num_proteins();
   if (first < 0 || first > N) return fail(x, DCP_EINVALPART, "first protein out of range");
   int const last = count < 0 ? N : std::min(N, first + count);
-  DcpProtein p;
-  for (int i = first; i < last; ++i)
+  int const n = last - first;
+  if (n <= 0) return 0;
+
+  std::vector<HostProfile> hps((size_t)n);
+  std::vector<size_t> off((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i)
   {
-    if ((rc = db.read_protein(i, p))) return fail(x, rc, "cannot read protein");
-    float *t, *r;
-    if ((rc = add_slot(x, p.core_size, p.accession.c_str(), &t, &r, nullptr))) return rc;
-    dcp_setup_profile(p.core_size, x->profiles.back().Kp, p.trans.data(), p.emission.data(), p.BMk.data(),
-                      p.null_emission.data(), p.bg_emission.data(), t, r);
+    int K = 0;
+    std::string acc;
+    if ((rc = db.read_protein_head(first + i, K, acc))) return fail(x, rc, "cannot read protein");
+    if ((rc = describe(x, K, acc.c_str(), hps[(size_t)i]))) return rc;
+    off[(size_t)i + 1] = off[(size_t)i] + profile_floats(hps[(size_t)i].Kp);
   }
+  if ((rc = ensure_pool(x, x->pool_used + off[(size_t)n]))) return rc;
+
+  size_t const chunk_floats = std::max<size_t>((size_t)64 << 20, profile_floats(DCP_MAX_CORE_SIZE)); // 256 MiB
+  float *stage[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  bool busy[2] = {false, false};
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(x->stream);
+    for (int b = 0; b < 2; ++b)
+    {
+      if (stage[b]) (void)hipHostFree(stage[b]);
+      if (done[b]) (void)hipEventDestroy(done[b]);
+    }
+  };
+  for (int b = 0; b < 2; ++b)
+  {
+    if (hipHostMalloc((void **)&stage[b], std::min(chunk_floats, off[(size_t)n]) * sizeof(float), hipHostMallocDefault) !=
+            hipSuccess ||
+        hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess)
+    {
+      cleanup();
+      return fail(x, DCP_ENOMEM, "cannot allocate pinned staging buffers");
+    }
+  }
+  int b = 0;
+  for (int i0 = 0; i0 < n;)
+  {
+    int i1 = i0 + 1;
+    while (i1 < n && off[(size_t)i1 + 1] - off[(size_t)i0] <= chunk_floats) ++i1;
+    if (busy[b] && hipEventSynchronize(done[b]) != hipSuccess)
+    {
+      cleanup();
+      return fail(x, DCP_EFUNCUSE, "staging copy failed");
+    }
+    float *buf = stage[b];
+    // plain threads, joined per chunk: no runtime is left spinning next to the HIP callbacks
+    std::atomic<int> next_protein{i0}, bad{0};
+    auto work = [&]() {
+      DcpProtein p;
+      for (int i = next_protein.fetch_add(1); i < i1; i = next_protein.fetch_add(1))
+      {
+        int r = db.read_protein(first + i, p);
+        if (r || p.core_size != hps[(size_t)i].K)
+        {
+          int expected = 0;
+          bad.compare_exchange_strong(expected, r ? r : DCP_EFDATA);
+          continue;
+        }
+        float *rows = buf + (off[(size_t)i] - off[(size_t)i0]);
+        float *trans = rows + (size_t)DCP_TABLE_SIZE * ((size_t)hps[(size_t)i].Kp + DCP_ROW_HDR);
+        dcp_setup_profile(p.core_size, hps[(size_t)i].Kp, p.trans.data(), p.emission.data(), p.BMk.data(),
+                          p.null_emission.data(), p.bg_emission.data(), trans, rows);
+      }
+    };
+    {
+      unsigned nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u, (unsigned)(i1 - i0)});
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+      work();
+      for (std::thread &t : pool) t.join();
+    }
+    if (bad)
+    {
+      cleanup();
+      return fail(x, bad, "cannot read protein");
+    }
+    size_t const floats = off[(size_t)i1] - off[(size_t)i0];
+    if (hipMemcpyAsync(x->d_pool.p + x->pool_used + off[(size_t)i0], buf, floats * sizeof(float), hipMemcpyHostToDevice,
+                       x->stream) != hipSuccess ||
+        hipEventRecord(done[b], x->stream) != hipSuccess)
+    {
+      cleanup();
+      return fail(x, DCP_EFUNCUSE, "staging copy failed");
+    }
+    busy[b] = true;
+    b ^= 1;
+    i0 = i1;
+  }
+  cleanup();
+  for (int i = 0; i < n; ++i)
+  {
+    hps[(size_t)i].pool_off = (int64_t)(x->pool_used + off[(size_t)i]);
+    x->profiles.push_back(hps[(size_t)i]);
+  }
+  x->pool_used += off[(size_t)n];
   return 0;
 }
 
@@ -442,12 +575,8 @@ int dcp_hip_commit_profiles(struct dcp_hip *x)
   if (!x) return DCP_EFUNCUSE;
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   if (x->committed == x->profiles.size()) return 0;
-  // simple policy: (re)upload the whole pool; profiles are added in bulk before a scan
+  // the tables are already in HBM; what is published here are the profile descriptors
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
-  HIP_TRY(x, x->d_pool.reserve(x->pool.size()), DCP_ENOMEM);
-  HIP_TRY(x, hipMemcpyAsync(x->d_pool.p, x->pool.data(), x->pool.size() * sizeof(float), hipMemcpyHostToDevice,
-                            x->stream),
-          DCP_EFUNCUSE);
   std::vector<DcpProfileDev> dev(x->profiles.size());
   for (size_t i = 0; i < dev.size(); ++i)
   {
@@ -466,17 +595,15 @@ int dcp_hip_commit_profiles(struct dcp_hip *x)
           DCP_EFUNCUSE);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
   x->committed = x->profiles.size();
-  x->committed_floats = x->pool.size();
   return 0;
 }
 
 void dcp_hip_clear_profiles(struct dcp_hip *x)
 {
   if (!x) return;
-  x->pool.clear();
+  x->pool_used = 0;
   x->profiles.clear();
   x->committed = 0;
-  x->committed_floats = 0;
 }
 
 int dcp_hip_encode(char const *data, int64_t n, uint8_t *out)
