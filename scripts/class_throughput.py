@@ -18,9 +18,38 @@ L = 1000
 reads = [random_seq(rng, L) for _ in range(16384)]
 eng.set_sequences(reads)
 eng.set_mode(True, False)
-for K in [int(a) for a in (sys.argv[1:] or "3 16 32 64 100 128 173 192 241 256 400 512 900 1024 1800 2048 4096".split())]:
+def real_like(K):
+    """A profile with the transition/emission structure of real Pfam models: the minifam
+    profiles (K = 173, 241, 162) concatenated and cut/tiled to K positions."""
+    from dcp_testlib import GOLDEN, oracle
+    from oracle.dcp_reader import read_dcp
+    from oracle.pyoracle import Profile
+
+    orc = oracle()
+    ps = [orc.setup_profile(q) for q in read_dcp(os.path.join(GOLDEN, "minifam.dcp")).proteins]
+    trans = np.concatenate([q.trans for q in ps], axis=1)
+    match = np.concatenate([q.match for q in ps], axis=1)
+    reps = (K + trans.shape[1] - 1) // trans.shape[1]
+    trans = np.tile(trans, (1, reps))[:, :K].copy()
+    match = np.tile(match, (1, reps))[:, :K].copy()
+    inf = np.float32(np.inf)
+    for t in (1, 3, 4, 6, 7):
+        col = trans[t]
+        col[np.isinf(col)] = np.float32(3.0)  # interior joins: a finite transition instead of the model start
+        col[0] = inf
+    for t in (2, 5):
+        col = trans[t]
+        col[np.isinf(col)] = np.float32(3.0)
+        col[K - 1] = inf
+    return Profile(K, np.ascontiguousarray(trans), np.ascontiguousarray(match), ps[0].null, ps[0].bg, f"REAL{K}")
+
+
+args = sys.argv[1:]
+real = "--real" in args
+args = [a for a in args if a != "--real"]
+for K in [int(a) for a in (args or "3 16 32 64 100 128 173 192 241 256 400 512 900 1024 1800 2048 4096".split())]:
     eng.clear_profiles()
-    p = synth_profile(rng, K)
+    p = real_like(K) if real else synth_profile(rng, K)
     eng.add_profile(p.K, p.trans, p.match, p.null, p.bg)
     eng.commit()
     nreads = int(min(len(reads), max(512, 3.0e9 / (K * L))))
