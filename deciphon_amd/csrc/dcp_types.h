@@ -21,6 +21,7 @@ struct DcpCodeRow
   uint32_t c[8];
 };
 
+#define DCP_SP_STRIDE 8 // floats per row of special-state values in a DP table: N,B,J,E,C,0,0,0
 #define DCP_ROW_HDR 4 // floats in front of every emission row: null[c], bg[c], 0, 0
 
 // A profile resident in HBM, in DP-parameter space (costs = -log-prob, +inf =

@@ -71,8 +71,8 @@ struct PathResult
 {
   int K = 0, L = 0;
   float score = 0;
-  size_t arena_off = 0;   // bytes into the device arena
-  size_t host_off = 0;    // bytes into host_arena once fetched
+  size_t trellis_off = 0;      // bytes into d_trellis, valid when has_trellis
+  bool has_trellis = false;    // the literal path kernel has run for this window
   bool trellis_on_host = false;
   std::vector<int32_t> state_ids, seqsizes;
 };
@@ -112,7 +112,10 @@ struct dcp_hip
   // problems / results
   DevBuf<DcpProblem> d_problems;
   DevBuf<float> d_out;
-  DevBuf<unsigned char> d_arena;
+  DevBuf<unsigned char> d_arena;   // DP tables of the fast path pass
+  DevBuf<unsigned char> d_trellis; // trellises of the literal path pass
+  std::vector<dcp_hip_window> path_wins; // the windows of the last dcp_hip_path
+  int path_redone = 0;                   // how many of them needed the literal pass
   DevBuf<uint32_t> d_steps;
   DevBuf<int64_t> d_step_off;
   DevBuf<int32_t> d_nsteps;
@@ -170,8 +173,10 @@ struct Staged
   size_t arena_bytes = 0;
 };
 
+enum ArenaKind { ARENA_NONE, ARENA_TRELLIS, ARENA_TABLE };
+
 // validates windows and builds the device problem list
-int stage(dcp_hip *x, int n, dcp_hip_window const *w, bool with_trellis, Staged &st)
+int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Staged &st)
 {
   if (n < 0 || (n > 0 && !w)) return fail(x, DCP_EFUNCUSE, "bad window array");
   if (x->committed != x->profiles.size()) return fail(x, DCP_EFUNCUSE, "profiles not committed");
@@ -197,10 +202,12 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, bool with_trellis, Staged 
     p.trellis = 0;
     max_s = std::max(max_s, p.xt_row);
     st.cells += (double)hp.K * (double)L;
-    if (with_trellis)
+    if (arena_kind != ARENA_NONE)
     {
       p.trellis = (int64_t)arena;
-      size_t bytes = ((size_t)L + 1) * 4 + ((size_t)L + 1) * (size_t)hp.K * 2;
+      size_t const bytes = arena_kind == ARENA_TRELLIS
+                               ? ((size_t)L + 1) * 4 + ((size_t)L + 1) * (size_t)hp.K * 2 // c-core/trellis.h:12-21
+                               : ((size_t)L + 1) * (DCP_SP_STRIDE + 3 * (size_t)hp.Kp) * 4; // DP table, traceback.h
       arena += (bytes + 15) & ~(size_t)15;
     }
   }
@@ -238,7 +245,7 @@ DcpLaunch launch_args(dcp_hip *x, Staged const &st, int c)
   a.code_rows = x->d_rows.p;
   a.xt_table = x->d_xt.p;
   a.out = x->d_out.p;
-  a.arena = x->d_arena.p;
+  a.arena = x->d_trellis.p;
   a.nprob = st.c_begin[c + 1] - st.c_begin[c];
   a.stream = x->stream;
   return a;
@@ -683,7 +690,7 @@ int dcp_hip_cost(struct dcp_hip *x, int n, struct dcp_hip_window const *w, float
   if (!x || (n > 0 && (!null_cost || !alt_cost))) return DCP_EFUNCUSE;
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   Staged st;
-  int rc = stage(x, n, w, false, st);
+  int rc = stage(x, n, w, ARENA_NONE, st);
   if (rc) return rc;
   if (n == 0) return 0;
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
@@ -706,7 +713,7 @@ int dcp_hip_cost_bench(struct dcp_hip *x, int n, struct dcp_hip_window const *w,
   if (!x || n <= 0 || reps <= 0 || !ms || !cells) return DCP_EFUNCUSE;
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   Staged st;
-  int rc = stage(x, n, w, false, st);
+  int rc = stage(x, n, w, ARENA_NONE, st);
   if (rc) return rc;
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   for (int i = 0; i < warmup; ++i)
@@ -745,7 +752,7 @@ int dcp_hip_stage(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
   if (!x || n <= 0) return DCP_EFUNCUSE;
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   Staged st;
-  int rc = stage(x, n, w, false, st);
+  int rc = stage(x, n, w, ARENA_NONE, st);
   if (rc) return rc;
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
@@ -795,31 +802,65 @@ int dcp_hip_fetch_staged(struct dcp_hip *x, float *null_cost, float *alt_cost)
   return 0;
 }
 
-int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
+namespace
 {
-  if (!x) return DCP_EFUNCUSE;
-  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
-  x->paths.clear();
-  Staged st;
-  int rc = stage(x, n, w, true, st);
-  if (rc) return rc;
-  if (n == 0) return 0;
-  HIP_TRY(x, x->d_out.reserve((size_t)n), DCP_ENOMEM);
-  HIP_TRY(x, x->d_arena.reserve(st.arena_bytes), DCP_ENOMEM);
-  if ((rc = launch_all(x, st, true))) return rc;
 
-  // trellis_unzip on the device: only the paths (about L/3 steps of 4 bytes) cross PCIe,
-  // not the trellises ((L+1)*(2K+4) bytes each)
-  // A path has at most L emitting steps; mute steps (S, B, E, T, D runs) are few in
-  // practice.  Paths that do not fit are unzipped by the host from the fetched trellis.
-  // DECIPHON_HIP_UNZIP_CAP (steps) overrides the capacity: a test hook for that fallback.
+// step buffers: a path has at most L emitting steps; mute steps (S, B, E, T, D runs) are few
+// in practice.  DECIPHON_HIP_UNZIP_CAP (steps) overrides the capacity: a test hook for the
+// overflow fallbacks.
+std::vector<int64_t> step_offsets(dcp_hip *x, Staged const &st, int n)
+{
   int64_t cap_override = 0;
   if (char const *e = getenv("DECIPHON_HIP_UNZIP_CAP")) cap_override = atoll(e);
-  std::vector<int64_t> step_off((size_t)n + 1, 0);
+  std::vector<int64_t> off((size_t)n + 1, 0);
   for (DcpProblem const &p : st.problems)
-    step_off[(size_t)p.out + 1] =
+    off[(size_t)p.out + 1] =
         cap_override > 0 ? cap_override : 2 * (int64_t)p.L + 2 * (int64_t)x->profiles[(size_t)p.profile].K + 64;
-  for (int i = 0; i < n; ++i) step_off[(size_t)i + 1] += step_off[(size_t)i];
+  for (int i = 0; i < n; ++i) off[(size_t)i + 1] += off[(size_t)i];
+  return off;
+}
+
+void unpack_steps(uint32_t const *s, int32_t ns, PathResult &r)
+{
+  r.state_ids.resize((size_t)ns);
+  r.seqsizes.resize((size_t)ns);
+  for (int32_t i = 0; i < ns; ++i)
+  {
+    r.state_ids[(size_t)i] = (int32_t)(s[i] & 0xffffu);
+    r.seqsizes[(size_t)i] = (int32_t)(s[i] >> 16);
+  }
+}
+
+int fetch_trellis(dcp_hip *x, int i)
+{
+  PathResult &r = x->paths[(size_t)i];
+  if (r.trellis_on_host) return 0;
+  std::vector<unsigned char> &buf = x->host_trellis[(size_t)i];
+  size_t const bytes = ((size_t)r.L + 1) * 4 + ((size_t)r.L + 1) * (size_t)r.K * 2;
+  buf.resize(bytes);
+  HIP_TRY(x, hipMemcpyAsync(buf.data(), x->d_trellis.p + r.trellis_off, bytes, hipMemcpyDeviceToHost, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  r.trellis_on_host = true;
+  return 0;
+}
+
+// The literal path pass (viterbi_path as the reference runs it, pass by pass, with the
+// trellis in HBM) + trellis_unzip on the device, for the windows path_wins[idx[..]].
+int path_literal(dcp_hip *x, std::vector<int> const &idx)
+{
+  int const n = (int)idx.size();
+  if (n == 0) return 0;
+  std::vector<dcp_hip_window> w((size_t)n);
+  for (int j = 0; j < n; ++j) w[(size_t)j] = x->path_wins[(size_t)idx[(size_t)j]];
+  Staged st;
+  int rc = stage(x, n, w.data(), ARENA_TRELLIS, st);
+  if (rc) return rc;
+  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, x->d_trellis.reserve(st.arena_bytes), DCP_ENOMEM);
+  if ((rc = launch_all(x, st, true))) return rc;
+
+  std::vector<int64_t> step_off = step_offsets(x, st, n);
   size_t const total_steps = (size_t)step_off[(size_t)n];
   HIP_TRY(x, x->d_steps.reserve(total_steps), DCP_ENOMEM);
   HIP_TRY(x, x->d_step_off.reserve((size_t)n + 1), DCP_ENOMEM);
@@ -845,38 +886,118 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
                             x->stream),
           DCP_EFUNCUSE);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
-  x->paths.resize((size_t)n);
-  x->host_trellis.assign((size_t)n, std::vector<unsigned char>());
+  // every earlier trellis offset pointed into the arena that was just rewritten
+  for (PathResult &r : x->paths) r.has_trellis = r.trellis_on_host = false;
+  for (DcpProblem const &p : st.problems)
+  {
+    int const i = idx[(size_t)p.out];
+    PathResult &r = x->paths[(size_t)i];
+    r.K = x->profiles[(size_t)p.profile].K;
+    r.L = p.L;
+    r.score = out[(size_t)p.out];
+    r.trellis_off = (size_t)p.trellis;
+    r.has_trellis = true;
+    r.trellis_on_host = false;
+    r.state_ids.clear();
+    r.seqsizes.clear();
+    int32_t const ns = nsteps[(size_t)p.out];
+    if (ns >= 0)
+      unpack_steps(steps.data() + step_off[(size_t)p.out + 1] - ns, ns, r);
+    else
+    {
+      // the device buffer was too small for this path: fetch the trellis and unzip here
+      if ((rc = fetch_trellis(x, i))) return rc;
+      uint32_t const *xn = reinterpret_cast<uint32_t const *>(x->host_trellis[(size_t)i].data());
+      uint16_t const *nd = reinterpret_cast<uint16_t const *>(xn + (r.L + 1));
+      if ((rc = dcp_unzip(r.K, r.L, xn, nd, r.state_ids, r.seqsizes))) return fail(x, rc, "trellis_unzip failed");
+    }
+  }
+  return 0;
+}
+
+// The fast path pass: the cost pass once more with every row's values kept in HBM, then a
+// traceback that reads the back-pointers off those values (traceback.h).  Windows whose
+// traceback meets an exact tie the values alone cannot resolve come back in `redo`.
+int path_fast(dcp_hip *x, std::vector<int> &redo)
+{
+  int const n = (int)x->path_wins.size();
+  Staged st;
+  int rc = stage(x, n, x->path_wins.data(), ARENA_TABLE, st);
+  if (rc) return rc;
+  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, x->d_arena.reserve(st.arena_bytes), DCP_ENOMEM);
+  for (int c = 0; c < DCP_NUM_CLASSES; ++c)
+  {
+    DcpLaunch a = launch_args(x, st, c);
+    a.arena = x->d_arena.p;
+    HIP_TRY(x, dcp_launch_cost_store(c, a), DCP_EFUNCUSE);
+  }
+  std::vector<int64_t> step_off = step_offsets(x, st, n);
+  size_t const total_steps = (size_t)step_off[(size_t)n];
+  HIP_TRY(x, x->d_steps.reserve(total_steps), DCP_ENOMEM);
+  HIP_TRY(x, x->d_step_off.reserve((size_t)n + 1), DCP_ENOMEM);
+  HIP_TRY(x, x->d_nsteps.reserve((size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, hipMemcpyAsync(x->d_step_off.p, step_off.data(), ((size_t)n + 1) * sizeof(int64_t),
+                            hipMemcpyHostToDevice, x->stream),
+          DCP_EFUNCUSE);
+  {
+    DcpLaunch a = launch_args(x, st, 0);
+    a.problems = x->d_problems.p;
+    a.nprob = n;
+    a.arena = x->d_arena.p;
+    HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p), DCP_EFUNCUSE);
+  }
+  std::vector<float> out(2 * (size_t)n);
+  std::vector<int32_t> nsteps((size_t)n);
+  std::vector<uint32_t> steps(total_steps);
+  HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipMemcpyAsync(nsteps.data(), x->d_nsteps.p, nsteps.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
+                            x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipMemcpyAsync(steps.data(), x->d_steps.p, total_steps * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                            x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
   for (DcpProblem const &p : st.problems)
   {
     PathResult &r = x->paths[(size_t)p.out];
     r.K = x->profiles[(size_t)p.profile].K;
     r.L = p.L;
-    r.score = out[(size_t)p.out];
-    r.arena_off = (size_t)p.trellis;
-    r.trellis_on_host = false;
+    r.score = out[2 * (size_t)p.out + 1]; // the alt score of the same DP
+    r.has_trellis = r.trellis_on_host = false;
     int32_t const ns = nsteps[(size_t)p.out];
     if (ns >= 0)
-    {
-      uint32_t const *s = steps.data() + step_off[(size_t)p.out + 1] - ns;
-      r.state_ids.resize((size_t)ns);
-      r.seqsizes.resize((size_t)ns);
-      for (int32_t i = 0; i < ns; ++i)
-      {
-        r.state_ids[(size_t)i] = (int32_t)(s[i] & 0xffffu);
-        r.seqsizes[(size_t)i] = (int32_t)(s[i] >> 16);
-      }
-    }
+      unpack_steps(steps.data() + step_off[(size_t)p.out + 1] - ns, ns, r);
     else
-    {
-      // the device buffer was too small for this path: fetch the trellis and unzip here
-      uint32_t const *xn;
-      uint16_t const *nd;
-      if ((rc = dcp_hip_path_trellis(x, p.out, &xn, &nd))) return rc;
-      if ((rc = dcp_unzip(r.K, r.L, xn, nd, r.state_ids, r.seqsizes))) return fail(x, rc, "trellis_unzip failed");
-    }
+      redo.push_back(p.out);
   }
+  std::sort(redo.begin(), redo.end());
   return 0;
+}
+
+} // namespace
+
+int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
+{
+  if (!x || n < 0 || (n > 0 && !w)) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  x->paths.clear();
+  x->path_wins.assign(w, w + n);
+  x->paths.resize((size_t)n);
+  x->host_trellis.assign((size_t)n, std::vector<unsigned char>());
+  if (n == 0) return 0;
+  std::vector<int> redo;
+  char const *mode = getenv("DECIPHON_HIP_PATH"); // "literal": skip the fast pass (tests, debugging)
+  if (mode && strcmp(mode, "literal") == 0)
+    for (int i = 0; i < n; ++i) redo.push_back(i);
+  else
+  {
+    int rc = path_fast(x, redo);
+    if (rc) return rc;
+  }
+  x->path_redone = (int)redo.size();
+  return path_literal(x, redo);
 }
 
 int dcp_hip_path_nsteps(struct dcp_hip const *x, int i)
@@ -898,23 +1019,25 @@ int dcp_hip_path_trellis(struct dcp_hip const *cx, int i, uint32_t const **xnode
 {
   dcp_hip *x = const_cast<dcp_hip *>(cx);
   if (!x || i < 0 || i >= (int)x->paths.size() || !xnodes || !nodes) return DCP_EFUNCUSE;
-  PathResult &r = x->paths[(size_t)i];
-  std::vector<unsigned char> &buf = x->host_trellis[(size_t)i];
-  if (!r.trellis_on_host) // trellises stay in HBM until somebody asks for one
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  if (!x->paths[(size_t)i].has_trellis)
   {
-    size_t const bytes = ((size_t)r.L + 1) * 4 + ((size_t)r.L + 1) * (size_t)r.K * 2;
-    buf.resize(bytes);
-    HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
-    HIP_TRY(x, hipMemcpyAsync(buf.data(), x->d_arena.p + r.arena_off, bytes, hipMemcpyDeviceToHost, x->stream),
-            DCP_EFUNCUSE);
-    HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
-    r.trellis_on_host = true;
+    // The fast path pass keeps no trellis.  Somebody wants one: run the literal pass for the
+    // whole batch once (its paths replace the fast ones; they are the same steps).
+    std::vector<int> all((size_t)x->paths.size());
+    for (size_t j = 0; j < all.size(); ++j) all[j] = (int)j;
+    int rc = path_literal(x, all);
+    if (rc) return rc;
   }
-  uint32_t const *xn = reinterpret_cast<uint32_t const *>(buf.data());
+  int rc = fetch_trellis(x, i);
+  if (rc) return rc;
+  uint32_t const *xn = reinterpret_cast<uint32_t const *>(x->host_trellis[(size_t)i].data());
   *xnodes = xn;
-  *nodes = reinterpret_cast<uint16_t const *>(xn + (r.L + 1));
+  *nodes = reinterpret_cast<uint16_t const *>(xn + (x->paths[(size_t)i].L + 1));
   return 0;
 }
+
+int dcp_hip_path_redone(struct dcp_hip const *x) { return x ? x->path_redone : 0; }
 
 float dcp_hip_path_score(struct dcp_hip const *x, int i)
 {

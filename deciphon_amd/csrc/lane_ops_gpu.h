@@ -304,6 +304,30 @@ template <> DCP_FN void load_row_q<4>(RowSrc const &r, lu voff, uint32_t soff, l
   out[3] = __uint_as_float(v.w);
 }
 
+// one DP-table row plane: the lane's Q values at row[lane*Q ..], rows padded to Kp
+template <int Q> DCP_FN void store_q(float *__restrict__ row, lu lane, lf const (&v)[Q])
+{
+  float *p = row + (size_t)lane * Q;
+  if (Q == 1) p[0] = v[0];
+  if (Q == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[Q > 1 ? 1 : 0]);
+  if (Q == 3)
+  {
+    p[0] = v[0];
+    p[1] = v[Q > 1 ? 1 : 0];
+    p[2] = v[Q > 2 ? 2 : 0];
+  }
+  if (Q == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[Q > 1 ? 1 : 0], v[Q > 2 ? 2 : 0], v[Q > 3 ? 3 : 0]);
+}
+
+DCP_FN void store_sp_lane0(float *__restrict__ p, lu lane, lf N, lf B, lf J, lf E, lf C)
+{
+  if (lane == 0)
+  {
+    *reinterpret_cast<float4 *>(p) = make_float4(N, B, J, E);
+    p[4] = C;
+  }
+}
+
 // trellis node words of one row: positions k = lane*Q + q < K
 template <int Q> DCP_FN void store_nodes_q(uint16_t *__restrict__ row, int K, lu lane, lu const (&w)[Q])
 {

@@ -303,8 +303,8 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
         hit_of.push_back(i);
         lrts.push_back(l);
       }
-      // path pass in slices bounded by trellis memory: (L+1)*(2K+4) bytes each
-      size_t const budget = (size_t)8 << 30;
+      // path pass in slices bounded by the HBM its DP tables take: (L+1)*(32 + 12*Kp) bytes each
+      size_t const budget = (size_t)16 << 30;
       for (size_t h0 = 0; h0 < hits.size();)
       {
         size_t h1 = h0, bytes = 0;
@@ -312,7 +312,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
         {
           size_t const L = (size_t)(hits[h1].stop - hits[h1].start);
           size_t const K = (size_t)dcp_hip_profile_core_size(x->eng, hits[h1].profile);
-          size_t const b = (L + 1) * (2 * K + 4);
+          size_t const b = (L + 1) * (32 + 12 * (2 * K + 64)); // Kp <= 2K + 64
           if (h1 > h0 && bytes + b > budget) break;
           bytes += b;
           ++h1;

@@ -39,9 +39,15 @@
 // some M_l[j] plus non-negative delete costs (costs are -log-probabilities), so
 // they never lower the minimum.
 // =============================================================================
-template <int Q, int W> struct CostWave
+// STORE = true additionally writes every row's final values to a DP table in HBM
+// (cells[l][{M,I,D}][Kp] and specials[l][8] = N,B,J,E,C) for the traceback of
+// traceback.h -- the fast path pass.
+template <int Q, int W, bool STORE = false> struct CostWave
 {
   Group<W> g;
+  float *__restrict__ tab_cells = nullptr; // [(L+1)][3][Kp]
+  float *__restrict__ tab_sp = nullptr;    // [(L+1)][DCP_SP_STRIDE]
+  int tabKp = 0;
   lf BM[Q], MM[Q], MI[Q], MD[Q], IM[Q], II[Q], DM[Q], DD[Q];
   lf Mpre[5][Q], Ipre[5][Q], Spre[5];
   lf em[5][Q];
@@ -126,6 +132,8 @@ template <int Q, int W> struct CostWave
     Spre[0] = lsel(l0, lf_splat(0.0f + SN), lsel(l3, lf_splat(-RR + RR), inf));
     X = lsel(l3, lf_splat(-RR), inf);
     E = DCP_INF;
+    tabKp = Kp;
+    if (STORE && tab_cells) store_row0(SB);
   }
 
   template <int P> DCP_FN void row(int l, int L)
@@ -201,6 +209,28 @@ template <int Q, int W> struct CostWave
       Ipre[P][q] = lmin(I[q] + II[q], M[q] + MI[q]);
     }
     Spre[P] = lmin(lf_splat(E) + sa, X + sb);
+    if (STORE)
+    {
+      float *row = tab_cells + (size_t)l * 3 * (size_t)tabKp;
+      store_q<Q>(row, g.lane, M);
+      store_q<Q>(row + tabKp, g.lane, I);
+      store_q<Q>(row + 2 * tabKp, g.lane, D);
+      float const C = g.get_lane(GS_X, X, 2);
+      store_sp_lane0(tab_sp + (size_t)l * DCP_SP_STRIDE, g.lane, lf_splat(N), B, lf_splat(J), lf_splat(E), lf_splat(C));
+    }
+  }
+
+  // row 0 of the DP table: S = 0 (implicit), B = SB, everything else +inf
+  DCP_FN void store_row0(float SB)
+  {
+    lf inf[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) inf[q] = lf_splat(DCP_INF);
+    store_q<Q>(tab_cells, g.lane, inf);
+    store_q<Q>(tab_cells + tabKp, g.lane, inf);
+    store_q<Q>(tab_cells + 2 * tabKp, g.lane, inf);
+    lf const i = lf_splat(DCP_INF);
+    store_sp_lane0(tab_sp, g.lane, i, lf_splat(SB), i, i, i);
   }
 
   // out[0] = viterbi_null(), out[1] = viterbi_cost()

@@ -28,6 +28,10 @@ hipError_t dcp_launch_path(int cls, DcpLaunch const &a);
 // trellis_unzip of every problem of a.problems (all classes): steps[step_off[out] .. step_off[out+1]) is the
 // buffer of problem `out`; its steps end at the buffer's end
 hipError_t dcp_launch_unzip(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps);
+// fast path pass: cost pass that stores each window's DP table at arena + problem.trellis, then the
+// traceback of every problem of a.problems (all classes) into steps / nsteps (as dcp_launch_unzip)
+hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a);
+hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps);
 // every problem of classes 0..3 (single-wave) in one launch
 hipError_t dcp_launch_cost_fused(DcpLaunch const &a);
 hipError_t dcp_launch_encode(unsigned char const *nt, int64_t const *seq_off, int64_t const *row_off, int nseq,

@@ -5,6 +5,7 @@
 // Problems of one launch share the kernel class (Q, W), K <= 64*Q*W.
 #include "lane_ops_gpu.h"
 #include "viterbi_body.h"
+#include "traceback.h"
 #include "viterbi_kernels.h"
 
 template <int Q, int W>
@@ -22,6 +23,218 @@ __global__ __launch_bounds__(64 * W) void dcp_cost_kernel(float const *__restric
   CostWave<Q, W> w;
   w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
   w.run(pb.L, out + 2 * (size_t)pb.out);
+}
+
+// Fast path pass, step 1: the cost pass that also leaves the DP table of its window in the
+// arena: float specials[(L+1)][8] followed by float cells[(L+1)][3][Kp].
+template <int Q, int W>
+__global__ __launch_bounds__(64 * W) void dcp_cost_store_kernel(float const *__restrict__ pool,
+                                                            DcpProfileDev const *__restrict__ profiles,
+                                                            DcpProblem const *__restrict__ problems,
+                                                            DcpCodeRow const *__restrict__ code_rows,
+                                                            float const *__restrict__ xt_table,
+                                                            unsigned char *__restrict__ arena,
+                                                            float *__restrict__ out, int nprob)
+{
+  int const p = (int)blockIdx.x;
+  if (p >= nprob) return;
+  DcpProblem const pb = problems[p];
+  DcpProfileDev const pf = profiles[pb.profile];
+  CostWave<Q, W, true> w;
+  w.tab_sp = reinterpret_cast<float *>(arena + pb.trellis);
+  w.tab_cells = w.tab_sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
+  w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
+  w.run(pb.L, out + 2 * (size_t)pb.out);
+}
+
+// Fast path pass, step 2: one WAVEFRONT walks one window's DP table back from T to S.
+// Same decisions as the scalar dcp_traceback() of traceback.h (which documents them and
+// is what the CPU tests exercise); here the candidates of the visited state are spread
+// over the lanes in the reference's order -- lane j = (5 - t) * names + name -- so that
+// one step costs two load round trips instead of a chain of them, and the first
+// candidate equal to the stored value is the lowest set bit of a ballot.
+__device__ int dcp_traceback_wave(DcpTraceIn const &in, uint32_t *buf, int64_t cap)
+{
+  enum
+  {
+    ST_M = 0 << 14, ST_I = 1 << 14, ST_D = 2 << 14, ST_X = 3 << 14,
+    ST_S = ST_X | 3, ST_N = ST_X | 4, ST_B = ST_X | 5, ST_E = ST_X | 6, ST_J = ST_X | 7, ST_C = ST_X | 8, ST_T = ST_X | 9,
+  };
+  float const INF = __builtin_inff();
+  int const lane = (int)(threadIdx.x & 63);
+  int const K = in.K, Kp = in.Kp;
+  size_t const stride = (size_t)Kp + DCP_ROW_HDR;
+  auto SP = [&](int l, int i) { return in.sp[(size_t)l * DCP_SP_STRIDE + i]; };
+  auto CELL = [&](int l, int s, int k) { return k < 0 ? INF : in.cells[((size_t)l * 3 + s) * (size_t)Kp + k]; };
+  auto TR = [&](int id, int k) { return in.trans[(size_t)id * Kp + k]; };
+  float const *xt = in.xt;
+
+  int state = ST_T, stage = in.L;
+  int64_t n = 0;
+  while (state != ST_S || stage)
+  {
+    int size = 0, prev = -1;
+    DcpCodeRow const cr = in.codes[stage];
+    if ((state & ST_X) == ST_X)
+    {
+      if (state == ST_T)
+      {
+        float const a = SP(stage, 3) + xt[DCP_ET], b = SP(stage, 4) + xt[DCP_CT];
+        if (a == b) return a < INF ? DCP_TB_TIE : DCP_TB_BAD;
+        prev = a < b ? ST_E : ST_C;
+      }
+      else if (state == ST_N || state == ST_J || state == ST_C)
+      {
+        int const self = state == ST_N ? 0 : state == ST_J ? 2 : 4;
+        float const target = SP(stage, self);
+        if (!(target < INF)) return DCP_TB_BAD;
+        float const t_in = state == ST_N ? xt[DCP_SN] : state == ST_J ? xt[DCP_EJ] : xt[DCP_EC];
+        float const t_self = state == ST_N ? xt[DCP_NN] : state == ST_J ? xt[DCP_JJ] : xt[DCP_CC];
+        int const t = 5 - (lane >> 1), which = lane & 1;
+        bool hit = false;
+        if (lane < 10 && t <= stage)
+        {
+          int const z = stage - t;
+          float const nil = in.rows[(size_t)cr.c[t - 1] * stride];
+          float const from = state == ST_N ? (z == 0 ? 0.0f : INF) : SP(z, 3);
+          float const cand = which == 0 ? (from + t_in) + nil : (SP(z, self) + t_self) + nil;
+          hit = cand == target;
+        }
+        unsigned long long const mask = __ballot(hit);
+        if (!mask) return DCP_TB_BAD;
+        int const j = __ffsll((long long)mask) - 1;
+        size = 5 - (j >> 1);
+        prev = (j & 1) ? state : (state == ST_N ? ST_S : ST_E);
+      }
+      else if (state == ST_B)
+      {
+        if (stage == 0) prev = ST_S;
+        else
+        {
+          float const target = SP(stage, 1);
+          int const eN = SP(stage, 0) + xt[DCP_NB] == target, eE = SP(stage, 3) + xt[DCP_EB] == target,
+                    eJ = SP(stage, 2) + xt[DCP_JB] == target;
+          if (eN + eE + eJ != 1 || !(target < INF)) return eN + eE + eJ > 1 ? DCP_TB_TIE : DCP_TB_BAD;
+          prev = eN ? ST_N : eE ? ST_E : ST_J;
+        }
+      }
+      else if (state == ST_E)
+      {
+        float const target = SP(stage, 3);
+        if (!(target < INF)) return DCP_TB_BAD;
+        int Qr = (K - 1) / DCP_REF_LANES + 1;
+        if (Qr < 2) Qr = 2;
+        int key = -1; // (reference lane << 16) | (65535 - k): highest lane, then lowest k
+        bool dtie = false;
+        for (int k = lane; k < K; k += 64)
+        {
+          dtie = dtie || CELL(stage, 2, k) == target;
+          if (CELL(stage, 0, k) == target)
+          {
+            int const cand = ((k / Qr) << 16) | (65535 - k);
+            key = cand > key ? cand : key;
+          }
+        }
+        if (__ballot(dtie)) return DCP_TB_TIE;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+        {
+          int const o = __shfl_xor(key, d);
+          key = o > key ? o : key;
+        }
+        if (key < 0) return DCP_TB_BAD;
+        prev = ST_M | ((65535 - (key & 0xffff)) + 1);
+      }
+      else
+        return DCP_TB_BAD;
+    }
+    else
+    {
+      int const k = (state & 0x3FFF) - 1;
+      int const kind = state & ST_X;
+      if (k < 0 || k >= K) return DCP_TB_BAD;
+      if (kind == ST_M)
+      {
+        float const target = CELL(stage, 0, k);
+        if (!(target < INF)) return DCP_TB_BAD;
+        int const t = 5 - (lane >> 2), name = lane & 3; // BM, MM, IM, DM
+        bool hit = false;
+        if (lane < 20 && t <= stage)
+        {
+          int const z = stage - t;
+          float const m = in.rows[(size_t)cr.c[t - 1] * stride + DCP_ROW_HDR + k];
+          float const x = name == 0 ? SP(z, 1) : CELL(z, name - 1, k - 1);
+          float const tr = TR(name == 0 ? DCP_BM : name == 1 ? DCP_MM : name == 2 ? DCP_IM : DCP_DM, k);
+          hit = (x + tr) + m == target;
+        }
+        unsigned long long const mask = __ballot(hit);
+        if (!mask) return DCP_TB_BAD;
+        int const j = __ffsll((long long)mask) - 1;
+        size = 5 - (j >> 2);
+        int const nm = j & 3;
+        prev = nm == 0 ? ST_B : (nm == 1 ? ST_M : nm == 2 ? ST_I : ST_D) | k;
+      }
+      else if (kind == ST_I)
+      {
+        float const target = CELL(stage, 1, k);
+        if (!(target < INF)) return DCP_TB_BAD;
+        int const t = 5 - (lane >> 1), name = lane & 1; // II, MI
+        bool hit = false;
+        if (lane < 10 && t <= stage)
+        {
+          int const z = stage - t;
+          float const bg = in.rows[(size_t)cr.c[t - 1] * stride + 1];
+          float const x = name == 0 ? CELL(z, 1, k) : CELL(z, 0, k);
+          float const tr = TR(name == 0 ? DCP_II : DCP_MI, k);
+          hit = (x + tr) + bg == target;
+        }
+        unsigned long long const mask = __ballot(hit);
+        if (!mask) return DCP_TB_BAD;
+        int const j = __ffsll((long long)mask) - 1;
+        size = 5 - (j >> 1);
+        prev = ((j & 1) ? ST_M : ST_I) | (k + 1);
+      }
+      else
+      {
+        float const a = CELL(stage, 0, k - 1) + TR(DCP_MD, k), b = CELL(stage, 2, k - 1) + TR(DCP_DD, k);
+        if (a == b) return a < INF ? DCP_TB_TIE : DCP_TB_BAD;
+        prev = (a < b ? ST_M : ST_D) | k;
+      }
+    }
+    if (n + 1 >= cap) return DCP_TB_OVERFLOW;
+    if (lane == 0) buf[cap - 1 - n] = (uint32_t)state | ((uint32_t)size << 16);
+    ++n;
+    state = prev;
+    stage -= size;
+    if (stage < 0) return DCP_TB_BAD;
+  }
+  if (n >= cap) return DCP_TB_OVERFLOW;
+  if (lane == 0) buf[cap - 1 - n] = (uint32_t)state;
+  return (int)(n + 1);
+}
+
+__global__ __launch_bounds__(64) void dcp_traceback_kernel(
+    float const *__restrict__ pool, DcpProfileDev const *__restrict__ profiles, DcpProblem const *__restrict__ problems,
+    DcpCodeRow const *__restrict__ code_rows, float const *__restrict__ xt_table,
+    unsigned char const *__restrict__ arena, uint32_t *__restrict__ steps, int64_t const *__restrict__ step_off,
+    int32_t *__restrict__ nsteps, int nprob)
+{
+  int const p = (int)blockIdx.x;
+  if (p >= nprob) return;
+  DcpProblem const pb = problems[p];
+  DcpProfileDev const pf = profiles[pb.profile];
+  DcpTraceIn in;
+  in.K = pf.K;
+  in.Kp = pf.Kp;
+  in.L = pb.L;
+  in.sp = reinterpret_cast<float const *>(arena + pb.trellis);
+  in.cells = in.sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
+  in.rows = pool + pf.rows_off;
+  in.trans = pool + pf.trans_off;
+  in.codes = code_rows + pb.code_row;
+  in.xt = xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE;
+  int const r = dcp_traceback_wave(in, steps + step_off[pb.out], step_off[pb.out + 1] - step_off[pb.out]);
+  if ((threadIdx.x & 63) == 0) nsteps[pb.out] = r;
 }
 
 // All single-wave classes in one launch: small scans (a few thousand windows spread
@@ -246,6 +459,38 @@ hipError_t dcp_launch_cost(int cls, DcpLaunch const &a)
   case 7: return launch_cost_qw<4, 16>(a);
   default: return hipErrorInvalidValue;
   }
+}
+
+template <int Q, int W> static hipError_t launch_store_qw(DcpLaunch const &a)
+{
+  hipLaunchKernelGGL((dcp_cost_store_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool,
+                     a.profiles, a.problems, a.code_rows, a.xt_table, a.arena, a.out, a.nprob);
+  return hipGetLastError();
+}
+
+hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a)
+{
+  if (a.nprob <= 0) return hipSuccess;
+  switch (cls)
+  {
+  case 0: return launch_store_qw<1, 1>(a);
+  case 1: return launch_store_qw<2, 1>(a);
+  case 2: return launch_store_qw<3, 1>(a);
+  case 3: return launch_store_qw<4, 1>(a);
+  case 4: return launch_store_qw<4, 2>(a);
+  case 5: return launch_store_qw<4, 4>(a);
+  case 6: return launch_store_qw<4, 8>(a);
+  case 7: return launch_store_qw<4, 16>(a);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps)
+{
+  if (a.nprob <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dcp_traceback_kernel, dim3((unsigned)a.nprob), dim3(64), 0, a.stream, a.pool, a.profiles, a.problems,
+                     a.code_rows, a.xt_table, a.arena, steps, step_off, nsteps, a.nprob);
+  return hipGetLastError();
 }
 
 hipError_t dcp_launch_cost_fused(DcpLaunch const &a)

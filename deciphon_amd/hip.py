@@ -71,6 +71,7 @@ def load_library() -> C.CDLL:
     L.dcp_hip_run_staged.argtypes = [vp, i32, f32p, C.POINTER(C.c_double)]
     L.dcp_hip_fetch_staged.argtypes = [vp, vp, vp]
     L.dcp_hip_path.argtypes = [vp, i32, vp]
+    L.dcp_hip_path_redone.argtypes = [vp]
     L.dcp_hip_path_nsteps.argtypes = [vp, i32]
     L.dcp_hip_path_steps.argtypes = [vp, i32, vp, vp]
     L.dcp_hip_path_trellis.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
@@ -251,23 +252,35 @@ class Engine:
         self._check(self.lib.dcp_hip_fetch_staged(self.h, _p(nul), _p(alt)))
         return nul, alt
 
-    def path(self, windows):
-        """-> list of dicts(score, state_ids, seqsizes, xnodes, nodes) -- viterbi_path + trellis_unzip."""
+    def path(self, windows, trellis: bool = True):
+        """viterbi_path + trellis_unzip -> list of dicts(score, state_ids, seqsizes[, xnodes, nodes]).
+        The steps are read first (they come from the fast pass); trellis=True then asks for the
+        packed back-pointers too, which makes the library run the literal pass for the batch."""
         n, arr = self._windows(windows)
         self._check(self.lib.dcp_hip_path(self.h, n, arr))
+        self.path_redone = self.lib.dcp_hip_path_redone(self.h)
         out = []
         for i in range(n):
             ns = self.lib.dcp_hip_path_nsteps(self.h, i)
             ids = np.zeros(ns, dtype=np.int32)
             sizes = np.zeros(ns, dtype=np.int32)
             self._check(self.lib.dcp_hip_path_steps(self.h, i, _p(ids), _p(sizes)))
+            out.append(dict(score=np.float32(self.lib.dcp_hip_path_score(self.h, i)), state_ids=ids, seqsizes=sizes))
+        if not trellis:
+            return out
+        for i in range(n):
             xn, nd = C.c_void_p(), C.c_void_p()
             self._check(self.lib.dcp_hip_path_trellis(self.h, i, C.byref(xn), C.byref(nd)))
             w = arr[i]
             L = w.stop - w.start
             K = self.core_size(w.profile)
-            xnodes = np.ctypeslib.as_array(C.cast(xn, C.POINTER(C.c_uint32)), shape=(L + 1,)).copy()
-            nodes = np.ctypeslib.as_array(C.cast(nd, C.POINTER(C.c_uint16)), shape=((L + 1) * K,)).copy()
-            out.append(dict(score=np.float32(self.lib.dcp_hip_path_score(self.h, i)), state_ids=ids,
-                            seqsizes=sizes, xnodes=xnodes, nodes=nodes))
+            out[i]["xnodes"] = np.ctypeslib.as_array(C.cast(xn, C.POINTER(C.c_uint32)), shape=(L + 1,)).copy()
+            out[i]["nodes"] = np.ctypeslib.as_array(C.cast(nd, C.POINTER(C.c_uint16)), shape=((L + 1) * K,)).copy()
+            # the literal pass has replaced the steps: they must be the very same path
+            ns = self.lib.dcp_hip_path_nsteps(self.h, i)
+            ids = np.zeros(ns, dtype=np.int32)
+            sizes = np.zeros(ns, dtype=np.int32)
+            self._check(self.lib.dcp_hip_path_steps(self.h, i, _p(ids), _p(sizes)))
+            out[i]["literal_state_ids"], out[i]["literal_seqsizes"] = ids, sizes
+            out[i]["literal_score"] = np.float32(self.lib.dcp_hip_path_score(self.h, i))
         return out

@@ -99,8 +99,16 @@ struct dcp_hip_window
 int dcp_hip_cost(struct dcp_hip *, int n, struct dcp_hip_window const *, float *null_cost, float *alt_cost);
 
 /* viterbi_path + trellis_unzip for n windows (c-core/thread.c:124-126).  Results
- * stay valid until the next dcp_hip_path / dcp_hip_del. */
+ * stay valid until the next dcp_hip_path / dcp_hip_del.
+ * The steps come from a fast pass (cost pass with the DP values kept in HBM + a traceback
+ * that picks, at every visited state, the first candidate equal to the stored minimum --
+ * the reference's strict-< rule); windows in which that meets an exact fp32 tie only the
+ * reference's pass order resolves are redone with the literal pass-by-pass kernel.  The
+ * trellis itself is produced (by the literal kernel, for the whole batch) only when
+ * dcp_hip_path_trellis is called.  DECIPHON_HIP_PATH=literal forces the literal pass. */
 int dcp_hip_path(struct dcp_hip *, int n, struct dcp_hip_window const *);
+/* how many windows of the last dcp_hip_path needed the literal pass */
+int dcp_hip_path_redone(struct dcp_hip const *);
 /* number of steps of window i's path (S ... T) */
 int dcp_hip_path_nsteps(struct dcp_hip const *, int i);
 /* state ids (c-core/state.h:9-25, state.c:92-96) and emission lengths of every step */

@@ -123,6 +123,15 @@ template <int Q> inline void load_row_q(RowSrc const &r, lu voff, uint32_t soff,
     }
 }
 
+template <int Q> inline void store_q(float *row, lu lane, lf const (&v)[Q])
+{
+  for (int q = 0; q < Q; ++q) EM_FOR row[lane.v[i_] * Q + q] = v[q].v[i_];
+}
+inline void store_sp_lane0(float *p, lu, lf N, lf B, lf J, lf E, lf C)
+{
+  p[0] = N.v[0]; p[1] = B.v[0]; p[2] = J.v[0]; p[3] = E.v[0]; p[4] = C.v[0];
+}
+
 template <int Q> inline void store_nodes_q(uint16_t *row, int K, lu lane, lu const (&w)[Q])
 {
   for (int q = 0; q < Q; ++q)

@@ -329,3 +329,37 @@ def test_device_unzip_and_host_fallback(engine, orc, monkeypatch):
         for r in (x, y):
             assert np.array_equal(r["state_ids"], ids) and np.array_equal(r["seqsizes"], sizes)
             assert np.array_equal(r["xnodes"], xo) and np.array_equal(r["nodes"], no)
+
+
+def test_fast_path_pass_equals_literal_pass(engine, orc):
+    """The path pass has two implementations: traceback from the stored DP values (default)
+    and the literal pass-by-pass kernel (on demand / on ties).  Same steps, same score; the
+    fast one may only give up (and be redone literally) where an exact tie needs pass order."""
+    rng = np.random.default_rng(41)
+    profs, seqs, quants = [], [], []
+    for it in range(60):
+        K = int(rng.choice([2, 3, 9, 33, 64, 65, 100, 173, 192, 241, 256, 300, 600, 1100]))
+        quant = [None, None, None, 0.5, 2.0, 8.0][it % 6]
+        profs.append(synth_profile(rng, K, quant, [0, 0.05, 0.3][it % 3]))
+        seqs.append(random_seq(rng, int(rng.integers(1, 70))))
+        quants.append(quant)
+    engine.clear_profiles()
+    for p in profs:
+        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    engine.commit()
+    engine.set_sequences(seqs)
+    engine.set_mode(True, False)
+    wins = [(i, i, 0, len(seqs[i])) for i in range(len(profs))]
+    res = engine.path(wins)
+    assert 0 < engine.path_redone < len(wins)  # quantised tables tie, continuous ones do not
+    for i, r in enumerate(res):
+        xt = orc.xtrans(max(len(seqs[i]) // 3, 1), True, False)
+        score, xo, no = orc.path(profs[i], xt, seqs[i])
+        ids, sizes = orc.unzip(profs[i].K, len(seqs[i]), xo, no)
+        assert np.array_equal(r["state_ids"], ids) and np.array_equal(r["seqsizes"], sizes), (i, profs[i].K, quants[i])
+        assert np.array_equal(r["literal_state_ids"], ids) and np.array_equal(r["literal_seqsizes"], sizes)
+        assert bits(r["score"]) == bits(score) == bits(r["literal_score"])
+        assert np.array_equal(r["xnodes"], xo) and np.array_equal(r["nodes"], no)
+    untied = [i for i, q in enumerate(quants) if q is None]
+    engine.path([wins[i] for i in untied], trellis=False)
+    assert engine.path_redone == 0  # continuous costs: the fast pass alone
