@@ -60,6 +60,68 @@ template <class T> struct DevBuf
   }
 };
 
+// DP tables of the fast path pass: chunks that are allocated as slices need them and kept until
+// the engine goes (the driver wipes VRAM that is freed, and an allocation that lands on memory
+// still being wiped waits for it at ~30 GB/s -- scripts/alloc_timing.py; growing without ever
+// freeing never meets that).  place() hands out device addresses, reset() starts a new slice.
+struct TableArena
+{
+  static constexpr size_t CHUNK = (size_t)12 << 30;
+  struct Chunk { unsigned char *p; size_t size, used; };
+  std::vector<Chunk> chunks;
+  size_t held = 0;      // bytes in all chunks
+  size_t placed = 0;    // bytes handed out since reset()
+  double alloc_ms = 0;  // time spent in hipMalloc since reset()
+  size_t cur = 0;
+  ~TableArena()
+  {
+    for (Chunk &c : chunks) (void)hipFree(c.p);
+  }
+  void reset()
+  {
+    for (Chunk &c : chunks) c.used = 0;
+    cur = 0;
+    placed = 0;
+    alloc_ms = 0;
+  }
+  // nullptr when `bytes` more would take the arena past `budget` (or the device is full)
+  unsigned char *place(size_t bytes, size_t budget)
+  {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (; cur < chunks.size(); ++cur)
+    {
+      Chunk &c = chunks[cur];
+      if (c.size - c.used >= bytes)
+      {
+        unsigned char *at = c.p + c.used;
+        c.used += bytes;
+        placed += bytes;
+        return at;
+      }
+    }
+    size_t want = std::max(bytes, std::min(CHUNK, budget > held ? budget - held : 0));
+    if (held + want > budget)
+    {
+      if (placed != 0) return nullptr; // the slice ends here
+      want = bytes;                    // a lone table is tried whatever the budget says
+    }
+    auto const t0 = std::chrono::steady_clock::now();
+    unsigned char *p = nullptr;
+    if (hipMalloc((void **)&p, want) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    double const ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    alloc_ms += ms;
+    if (getenv("DECIPHON_HIP_TIMING")) fprintf(stderr, "TableArena: chunk %zu, %.2f GB in %.1f ms\n", chunks.size(), (double)want / 1e9, ms);
+    chunks.push_back(Chunk{p, want, bytes});
+    held += want;
+    placed += bytes;
+    return p;
+  }
+};
+
 struct HostProfile
 {
   int K, Kp, Q, W, cls;
@@ -112,12 +174,15 @@ struct dcp_hip
   // problems / results
   DevBuf<DcpProblem> d_problems;
   DevBuf<float> d_out;
-  DevBuf<unsigned char> d_arena;   // DP tables of the fast path pass
+  TableArena tables;               // DP tables of the fast path pass
+  std::vector<int64_t> table_addr; // per window of the slice being staged (device addresses)
+  std::vector<int> path_order;     // fast path pass: request windows, slowest first
+  std::vector<dcp_hip_window> path_sorted;
   DevBuf<unsigned char> d_trellis; // trellises of the literal path pass
   std::vector<dcp_hip_window> path_wins; // the windows of the last dcp_hip_path
   int path_redone = 0;                   // how many of them needed the literal pass
-  DevBuf<uint32_t> d_steps;
-  DevBuf<int64_t> d_step_off;
+  DevBuf<uint32_t> d_steps, d_compact;
+  DevBuf<int64_t> d_step_off, d_compact_off;
   DevBuf<int32_t> d_nsteps;
   std::vector<std::vector<unsigned char>> host_trellis; // fetched on demand, one per window
   std::vector<PathResult> paths;
@@ -175,6 +240,9 @@ struct Staged
 
 enum ArenaKind { ARENA_NONE, ARENA_TRELLIS, ARENA_TABLE };
 
+// DP table of one window: float specials[(L+1)][8], float cells[(L+1)][3][Kp] (traceback.h)
+size_t table_bytes(int L, int Kp) { return ((size_t)L + 1) * (DCP_SP_STRIDE + 3 * (size_t)Kp) * 4; }
+
 // validates windows and builds the device problem list
 int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Staged &st)
 {
@@ -204,10 +272,11 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
     st.cells += (double)hp.K * (double)L;
     if (arena_kind != ARENA_NONE)
     {
-      p.trellis = (int64_t)arena;
       size_t const bytes = arena_kind == ARENA_TRELLIS
                                ? ((size_t)L + 1) * 4 + ((size_t)L + 1) * (size_t)hp.K * 2 // c-core/trellis.h:12-21
-                               : ((size_t)L + 1) * (DCP_SP_STRIDE + 3 * (size_t)hp.Kp) * 4; // DP table, traceback.h
+                               : table_bytes(L, hp.Kp);
+      // trellises: offsets into d_trellis; DP tables: addresses the caller placed in x->tables
+      p.trellis = arena_kind == ARENA_TRELLIS ? (int64_t)arena : x->table_addr[(size_t)i];
       arena += (bytes + 15) & ~(size_t)15;
     }
   }
@@ -820,6 +889,33 @@ std::vector<int64_t> step_offsets(dcp_hip *x, Staged const &st, int n)
   return off;
 }
 
+// Brings the step counts and then only the steps actually written to the host:
+// steps[compact[i] .. compact[i+1]) are window i's (empty where nsteps[i] < 0).
+int fetch_steps(dcp_hip *x, int n, std::vector<int32_t> &nsteps, std::vector<int64_t> &compact,
+                std::vector<uint32_t> &steps)
+{
+  nsteps.resize((size_t)n);
+  HIP_TRY(x, hipMemcpyAsync(nsteps.data(), x->d_nsteps.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  compact.assign((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i) compact[(size_t)i + 1] = compact[(size_t)i] + (nsteps[(size_t)i] > 0 ? nsteps[(size_t)i] : 0);
+  size_t const total = (size_t)compact[(size_t)n];
+  steps.resize(total);
+  if (!total) return 0;
+  HIP_TRY(x, x->d_compact_off.reserve((size_t)n + 1), DCP_ENOMEM);
+  HIP_TRY(x, x->d_compact.reserve(total), DCP_ENOMEM);
+  HIP_TRY(x, hipMemcpyAsync(x->d_compact_off.p, compact.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
+                            x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, dcp_launch_compact_steps(x->d_steps.p, x->d_step_off.p, x->d_compact_off.p, x->d_compact.p, n, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipMemcpyAsync(steps.data(), x->d_compact.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  return 0;
+}
+
 void unpack_steps(uint32_t const *s, int32_t ns, PathResult &r)
 {
   r.state_ids.resize((size_t)ns);
@@ -875,17 +971,12 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
     HIP_TRY(x, dcp_launch_unzip(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p), DCP_EFUNCUSE);
   }
   std::vector<float> out((size_t)n);
-  std::vector<int32_t> nsteps((size_t)n);
-  std::vector<uint32_t> steps(total_steps);
+  std::vector<int32_t> nsteps;
+  std::vector<int64_t> compact;
+  std::vector<uint32_t> steps;
   HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
-  HIP_TRY(x, hipMemcpyAsync(nsteps.data(), x->d_nsteps.p, nsteps.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
-                            x->stream),
-          DCP_EFUNCUSE);
-  HIP_TRY(x, hipMemcpyAsync(steps.data(), x->d_steps.p, total_steps * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                            x->stream),
-          DCP_EFUNCUSE);
-  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  if ((rc = fetch_steps(x, n, nsteps, compact, steps))) return rc;
   // every earlier trellis offset pointed into the arena that was just rewritten
   for (PathResult &r : x->paths) r.has_trellis = r.trellis_on_host = false;
   for (DcpProblem const &p : st.problems)
@@ -902,7 +993,7 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
     r.seqsizes.clear();
     int32_t const ns = nsteps[(size_t)p.out];
     if (ns >= 0)
-      unpack_steps(steps.data() + step_off[(size_t)p.out + 1] - ns, ns, r);
+      unpack_steps(steps.data() + compact[(size_t)p.out], ns, r);
     else
     {
       // the device buffer was too small for this path: fetch the trellis and unzip here
@@ -918,20 +1009,43 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
 // The fast path pass: the cost pass once more with every row's values kept in HBM, then a
 // traceback that reads the back-pointers off those values (traceback.h).  Windows whose
 // traceback meets an exact tie the values alone cannot resolve come back in `redo`.
-int path_fast(dcp_hip *x, std::vector<int> &redo)
+// DECIPHON_HIP_TIMING=1: phase times of the path pass on stderr (synchronises between phases)
+struct PathTimer
 {
-  int const n = (int)x->path_wins.size();
+  bool on = getenv("DECIPHON_HIP_TIMING") != nullptr;
+  hipStream_t stream;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  std::string line;
+  explicit PathTimer(hipStream_t s) : stream(s) {}
+  void lap(char const *what)
+  {
+    if (!on) return;
+    (void)hipStreamSynchronize(stream);
+    auto const now = std::chrono::steady_clock::now();
+    char buf[64];
+    snprintf(buf, sizeof buf, " %s %.1f ms", what, std::chrono::duration<double, std::milli>(now - t).count());
+    line += buf;
+    t = now;
+  }
+};
+
+// windows [b, e) of x->path_sorted (window i there is window x->path_order[i] of the request)
+int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
+{
+  int const n = e - b;
+  PathTimer tm(x->stream);
   Staged st;
-  int rc = stage(x, n, x->path_wins.data(), ARENA_TABLE, st);
+  int rc = stage(x, n, x->path_sorted.data() + b, ARENA_TABLE, st);
   if (rc) return rc;
+  tm.lap("stage");
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
-  HIP_TRY(x, x->d_arena.reserve(st.arena_bytes), DCP_ENOMEM);
   for (int c = 0; c < DCP_NUM_CLASSES; ++c)
   {
     DcpLaunch a = launch_args(x, st, c);
-    a.arena = x->d_arena.p;
+    a.arena = nullptr; // DcpProblem::trellis holds the table's address
     HIP_TRY(x, dcp_launch_cost_store(c, a), DCP_EFUNCUSE);
   }
+  tm.lap("cost+store");
   std::vector<int64_t> step_off = step_offsets(x, st, n);
   size_t const total_steps = (size_t)step_off[(size_t)n];
   HIP_TRY(x, x->d_steps.reserve(total_steps), DCP_ENOMEM);
@@ -944,36 +1058,53 @@ int path_fast(dcp_hip *x, std::vector<int> &redo)
     DcpLaunch a = launch_args(x, st, 0);
     a.problems = x->d_problems.p;
     a.nprob = n;
-    a.arena = x->d_arena.p;
+    a.arena = nullptr;
     HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p), DCP_EFUNCUSE);
   }
+  tm.lap("traceback");
   std::vector<float> out(2 * (size_t)n);
-  std::vector<int32_t> nsteps((size_t)n);
-  std::vector<uint32_t> steps(total_steps);
+  std::vector<int32_t> nsteps;
+  std::vector<int64_t> compact;
+  std::vector<uint32_t> steps;
   HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
-  HIP_TRY(x, hipMemcpyAsync(nsteps.data(), x->d_nsteps.p, nsteps.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
-                            x->stream),
-          DCP_EFUNCUSE);
-  HIP_TRY(x, hipMemcpyAsync(steps.data(), x->d_steps.p, total_steps * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                            x->stream),
-          DCP_EFUNCUSE);
-  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  if ((rc = fetch_steps(x, n, nsteps, compact, steps))) return rc;
+  tm.lap("fetch");
   for (DcpProblem const &p : st.problems)
   {
-    PathResult &r = x->paths[(size_t)p.out];
+    PathResult &r = x->paths[(size_t)x->path_order[(size_t)(b + p.out)]];
     r.K = x->profiles[(size_t)p.profile].K;
     r.L = p.L;
     r.score = out[2 * (size_t)p.out + 1]; // the alt score of the same DP
     r.has_trellis = r.trellis_on_host = false;
     int32_t const ns = nsteps[(size_t)p.out];
     if (ns >= 0)
-      unpack_steps(steps.data() + step_off[(size_t)p.out + 1] - ns, ns, r);
+      unpack_steps(steps.data() + compact[(size_t)p.out], ns, r);
     else
-      redo.push_back(p.out);
+      redo.push_back(x->path_order[(size_t)(b + p.out)]);
   }
-  std::sort(redo.begin(), redo.end());
+  tm.lap("unpack");
+  if (tm.on)
+    fprintf(stderr, "dcp_hip_path: %d windows, tables %.2f GB of %.2f GB held (hipMalloc %.1f ms), %zu steps, %zu to redo;%s\n",
+            n, (double)x->tables.placed / 1e9, (double)x->tables.held / 1e9, x->tables.alloc_ms, steps.size(),
+            redo.size(), tm.line.c_str());
   return 0;
+}
+
+// HBM the fast pass fills with DP tables.  A slice takes as long as its longest window however
+// few windows it holds, so more memory means fewer, fuller slices -- but VRAM is cleared when it
+// is allocated (35 GB/s, scripts/alloc_timing.py), so an arena sized for the whole request costs
+// more than the slices it saves unless the engine lives long.  Default: what dcp_hip_path_reserve
+// set aside, at least 24 GB.  DECIPHON_HIP_PATH_BUDGET_MB overrides.
+size_t path_budget(dcp_hip *x)
+{
+  if (char const *e = getenv("DECIPHON_HIP_PATH_BUDGET_MB")) return (size_t)std::max(atol(e), 1L) << 20;
+  size_t const want = std::max(x->tables.held, 2 * TableArena::CHUNK);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return want;
+  size_t const margin = (size_t)6 << 30; // steps, trellis redo's, the caller's own buffers
+  size_t const avail = free_b + x->tables.held;
+  return std::max(std::min(want, avail > 2 * margin ? avail - margin : avail / 2), (size_t)256 << 20);
 }
 
 } // namespace
@@ -993,11 +1124,65 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
     for (int i = 0; i < n; ++i) redo.push_back(i);
   else
   {
-    int rc = path_fast(x, redo);
-    if (rc) return rc;
+    // slowest windows first, so that the slices of quick windows do not each wait for a slow one
+    // (a window's time is its rows times its class's time per row)
+    std::vector<double> cost((size_t)n);
+    for (int i = 0; i < n; ++i)
+    {
+      if (w[i].profile < 0 || w[i].profile >= (int)x->profiles.size()) return fail(x, DCP_EFUNCUSE, "bad profile index");
+      if (w[i].stop < w[i].start) return fail(x, DCP_EFUNCUSE, "bad window range");
+      int const W = x->profiles[(size_t)w[i].profile].W;
+      cost[(size_t)i] = (double)(w[i].stop - w[i].start) * (W == 1 ? 1.0 : W == 2 ? 2.0 : W == 4 ? 2.5 : W == 8 ? 3.0 : 4.0);
+    }
+    x->path_order.resize((size_t)n);
+    for (int i = 0; i < n; ++i) x->path_order[(size_t)i] = i;
+    std::stable_sort(x->path_order.begin(), x->path_order.end(),
+                     [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
+    x->path_sorted.resize((size_t)n);
+    for (int i = 0; i < n; ++i) x->path_sorted[(size_t)i] = w[x->path_order[(size_t)i]];
+    // slices bounded by the HBM their DP tables take
+    size_t const budget = path_budget(x);
+    dcp_hip_window const *ws = x->path_sorted.data();
+    for (int b = 0; b < n;)
+    {
+      int e = b;
+      x->tables.reset();
+      x->table_addr.clear();
+      while (e < n)
+      {
+        unsigned char *at =
+            x->tables.place(table_bytes(ws[e].stop - ws[e].start, x->profiles[(size_t)ws[e].profile].Kp), budget);
+        if (!at) break;
+        x->table_addr.push_back((int64_t)(uintptr_t)at);
+        ++e;
+      }
+      if (e == b) return fail(x, DCP_ENOMEM, "a window's DP table does not fit the device memory left");
+      int rc = path_fast(x, b, e, redo);
+      if (rc) return rc;
+      b = e;
+    }
+    std::sort(redo.begin(), redo.end());
   }
   x->path_redone = (int)redo.size();
   return path_literal(x, redo);
+}
+
+int dcp_hip_path_reserve(struct dcp_hip *x, int64_t bytes)
+{
+  if (!x || bytes < 0) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  x->tables.reset();
+  // place() allocates chunk after chunk until the arena holds `bytes`
+  while (x->tables.held < (size_t)bytes)
+  {
+    size_t const step = std::min(TableArena::CHUNK, (size_t)bytes - x->tables.held);
+    size_t const before = x->tables.held;
+    x->tables.cur = x->tables.chunks.size(); // past every chunk: force a new one
+    if (!x->tables.place(step, x->tables.held + step) || x->tables.held == before)
+      return fail(x, DCP_ENOMEM, "dcp_hip_path_reserve: hipMalloc failed");
+  }
+  x->tables.reset();
+  return 0;
 }
 
 int dcp_hip_path_nsteps(struct dcp_hip const *x, int i)

@@ -28,6 +28,7 @@
 #include <string.h>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
 #include <vector>
 
 struct dcp_batch
@@ -176,6 +177,13 @@ int setup_common(dcp_scan *x, char const *dbfile, int device, int index, int npa
   x->eng = dcp_hip_new(device);
   if (!x->eng) return raise(DCP_EFUNCUSE, __func__, "no usable HIP device (there is no CPU fallback)");
   x->device = device;
+  {
+    // HBM for the path pass's DP tables, first: VRAM is cleared on allocation, in the background,
+    // and the clearing then overlaps the database load and the first cost pass.  Best effort:
+    // dcp_hip_path allocates what it needs anyway.
+    char const *mb = getenv("DECIPHON_HIP_PATH_BUDGET_MB");
+    (void)dcp_hip_path_reserve(x->eng, mb ? (int64_t)std::max(atol(mb), 1L) << 20 : (int64_t)24 << 30);
+  }
   if (x->num_proteins > 0)
   {
     if ((rc = dcp_hip_load_dcp(x->eng, dbfile, x->index_offset, x->num_proteins)))
@@ -303,39 +311,53 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
         hit_of.push_back(i);
         lrts.push_back(l);
       }
-      // path pass in slices bounded by the HBM its DP tables take: (L+1)*(32 + 12*Kp) bytes each
-      size_t const budget = (size_t)16 << 30;
+      // one path pass per round (the engine slices it by the HBM its DP tables take)
       for (size_t h0 = 0; h0 < hits.size();)
       {
-        size_t h1 = h0, bytes = 0;
-        while (h1 < hits.size())
-        {
-          size_t const L = (size_t)(hits[h1].stop - hits[h1].start);
-          size_t const K = (size_t)dcp_hip_profile_core_size(x->eng, hits[h1].profile);
-          size_t const b = (L + 1) * (32 + 12 * (2 * K + 64)); // Kp <= 2K + 64
-          if (h1 > h0 && bytes + b > budget) break;
-          bytes += b;
-          ++h1;
-        }
+        size_t const h1 = hits.size();
         nhits += h1 - h0;
         ph.windows += ph.lap();
         if ((rc = dcp_hip_path(x->eng, (int)(h1 - h0), hits.data() + h0)))
           return raise(rc, __func__, dcp_hip_strerror(x->eng));
         ph.path += ph.lap();
+        // hit spans first (they move the window chains), then the rows, formatted by up to
+        // 16 host threads (a row is a few thousand short appends)
+        struct Job { size_t h; DcpHit hit; std::vector<int32_t> ids, sizes; };
+        std::vector<Job> jobs;
         for (size_t h = h0; h < h1; ++h)
         {
           int const n = dcp_hip_path_nsteps(x->eng, (int)(h - h0));
-          std::vector<int32_t> ids((size_t)n), sizes((size_t)n);
-          if ((rc = dcp_hip_path_steps(x->eng, (int)(h - h0), ids.data(), sizes.data()))) return raise(rc, __func__);
-          DcpHit hit;
-          if (!dcp_find_hit(ids, sizes, hit)) continue;
-          Pair &pr = pairs[owner[hit_of[h]]];
-          pr.win.last_hit_pos = hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
-          dcp_batch::Seq const &seq = batch->seqs[(size_t)pr.seq];
-          rows.push_back(Row{pr.profile, pr.seq, pr.win.idx,
-                             format_row(seq, pr.win.idx, pr.win.start, pr.win.stop, hit,
-                                        dcp_hip_profile_accession(x->eng, pr.profile), x->abc_name.c_str(),
-                                        lrts[h], ids, sizes)});
+          Job j;
+          j.h = h;
+          j.ids.resize((size_t)n);
+          j.sizes.resize((size_t)n);
+          if ((rc = dcp_hip_path_steps(x->eng, (int)(h - h0), j.ids.data(), j.sizes.data()))) return raise(rc, __func__);
+          if (!dcp_find_hit(j.ids, j.sizes, j.hit)) continue;
+          pairs[owner[hit_of[h]]].win.last_hit_pos = j.hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
+          jobs.push_back(std::move(j));
+        }
+        size_t const base = rows.size();
+        rows.resize(base + jobs.size());
+        std::atomic<size_t> next_job{0};
+        auto work = [&]() {
+          for (size_t k = next_job.fetch_add(1); k < jobs.size(); k = next_job.fetch_add(1))
+          {
+            Job const &j = jobs[k];
+            Pair const &pr = pairs[owner[hit_of[j.h]]];
+            dcp_batch::Seq const &seq = batch->seqs[(size_t)pr.seq];
+            rows[base + k] = Row{pr.profile, pr.seq, pr.win.idx,
+                                 format_row(seq, pr.win.idx, pr.win.start, pr.win.stop, j.hit,
+                                            dcp_hip_profile_accession(x->eng, pr.profile), x->abc_name.c_str(),
+                                            lrts[j.h], j.ids, j.sizes)};
+          }
+        };
+        {
+          unsigned nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
+                                                  (unsigned)std::max<size_t>(jobs.size() / 8, 1)});
+          std::vector<std::thread> pool;
+          for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+          work();
+          for (std::thread &t : pool) t.join();
         }
         h0 = h1;
         ph.rows += ph.lap();

@@ -133,7 +133,7 @@ template <int Q, int W, bool STORE = false> struct CostWave
     X = lsel(l3, lf_splat(-RR), inf);
     E = DCP_INF;
     tabKp = Kp;
-    if (STORE && tab_cells) store_row0(SB);
+    if (STORE) store_row0(SB);
   }
 
   template <int P> DCP_FN void row(int l, int L)

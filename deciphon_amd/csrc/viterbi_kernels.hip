@@ -41,7 +41,8 @@ __global__ __launch_bounds__(64 * W) void dcp_cost_store_kernel(float const *__r
   DcpProblem const pb = problems[p];
   DcpProfileDev const pf = profiles[pb.profile];
   CostWave<Q, W, true> w;
-  w.tab_sp = reinterpret_cast<float *>(arena + pb.trellis);
+  // integer arithmetic: the engine passes arena = 0 and absolute table addresses in pb.trellis
+  w.tab_sp = reinterpret_cast<float *>((uintptr_t)arena + (uintptr_t)pb.trellis);
   w.tab_cells = w.tab_sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
   w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
   w.run(pb.L, out + 2 * (size_t)pb.out);
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64) void dcp_traceback_kernel(
   in.K = pf.K;
   in.Kp = pf.Kp;
   in.L = pb.L;
-  in.sp = reinterpret_cast<float const *>(arena + pb.trellis);
+  in.sp = reinterpret_cast<float const *>((uintptr_t)arena + (uintptr_t)pb.trellis);
   in.cells = in.sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
   in.rows = pool + pf.rows_off;
   in.trans = pool + pf.trans_off;
@@ -400,6 +401,29 @@ __global__ void dcp_unzip_kernel(DcpProfileDev const *__restrict__ profiles, Dcp
   else
     bad = true;
   nsteps[pb.out] = bad ? -1 : (int32_t)n;
+}
+
+// Packs the steps of all windows back to back (window i: compact_off[i] .. compact_off[i+1])
+// so that one small D2H copy carries every path: the per-window buffers are sized for the
+// worst case and mostly empty.
+__global__ void dcp_compact_steps_kernel(uint32_t const *__restrict__ steps, int64_t const *__restrict__ step_off,
+                                         int64_t const *__restrict__ compact_off, uint32_t *__restrict__ out, int n)
+{
+  int const i = (int)blockIdx.x;
+  if (i >= n) return;
+  int64_t const count = compact_off[i + 1] - compact_off[i];
+  uint32_t const *src = steps + step_off[i + 1] - count; // the steps end at the buffer's end
+  uint32_t *dst = out + compact_off[i];
+  for (int64_t j = threadIdx.x; j < count; j += blockDim.x) dst[j] = src[j];
+}
+
+hipError_t dcp_launch_compact_steps(uint32_t const *steps, int64_t const *step_off, int64_t const *compact_off,
+                                    uint32_t *out, int n, hipStream_t stream)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dcp_compact_steps_kernel, dim3((unsigned)n), dim3(256), 0, stream, steps, step_off, compact_off,
+                     out, n);
+  return hipGetLastError();
 }
 
 hipError_t dcp_launch_unzip(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps)

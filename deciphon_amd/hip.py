@@ -72,6 +72,7 @@ def load_library() -> C.CDLL:
     L.dcp_hip_fetch_staged.argtypes = [vp, vp, vp]
     L.dcp_hip_path.argtypes = [vp, i32, vp]
     L.dcp_hip_path_redone.argtypes = [vp]
+    L.dcp_hip_path_reserve.argtypes = [vp, C.c_int64]
     L.dcp_hip_path_nsteps.argtypes = [vp, i32]
     L.dcp_hip_path_steps.argtypes = [vp, i32, vp, vp]
     L.dcp_hip_path_trellis.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
@@ -251,6 +252,10 @@ class Engine:
         alt = np.zeros(self._staged_n, dtype=np.float32)
         self._check(self.lib.dcp_hip_fetch_staged(self.h, _p(nul), _p(alt)))
         return nul, alt
+
+    def path_reserve(self, nbytes: int):
+        """Set HBM aside for the path pass's DP tables now (its clearing overlaps what follows)."""
+        self._check(self.lib.dcp_hip_path_reserve(self.h, int(nbytes)))
 
     def path(self, windows, trellis: bool = True):
         """viterbi_path + trellis_unzip -> list of dicts(score, state_ids, seqsizes[, xnodes, nodes]).

@@ -363,3 +363,63 @@ def test_fast_path_pass_equals_literal_pass(engine, orc):
     untied = [i for i, q in enumerate(quants) if q is None]
     engine.path([wins[i] for i in untied], trellis=False)
     assert engine.path_redone == 0  # continuous costs: the fast pass alone
+
+
+def test_path_pass_slices_by_table_memory(engine, orc, monkeypatch):
+    """dcp_hip_path cuts a large request into slices whose DP tables fit the HBM budget;
+    the slicing must not show in the results (forced here with a 1 MB budget)."""
+    rng = np.random.default_rng(43)
+    profs = [synth_profile(rng, K, None, 0.05) for K in (40, 173, 300, 700)]
+    seqs = [random_seq(rng, int(rng.integers(150, 400))) for _ in range(12)]
+    engine.clear_profiles()
+    for p in profs:
+        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    engine.commit()
+    engine.set_sequences(seqs)
+    engine.set_mode(True, False)
+    wins = [(p, s, 0, len(seqs[s])) for s in range(len(seqs)) for p in range(len(profs))]
+    whole = engine.path(wins, trellis=False)
+    monkeypatch.setenv("DECIPHON_HIP_PATH_BUDGET_MB", "1")
+    sliced = engine.path(wins, trellis=False)
+    monkeypatch.delenv("DECIPHON_HIP_PATH_BUDGET_MB")
+    for (p, s, _, _), a, b in zip(wins, whole, sliced):
+        xt = orc.xtrans(max(len(seqs[s]) // 3, 1), True, False)
+        score, xo, no = orc.path(profs[p], xt, seqs[s])
+        ids, sizes = orc.unzip(profs[p].K, len(seqs[s]), xo, no)
+        for r in (a, b):
+            assert np.array_equal(r["state_ids"], ids) and np.array_equal(r["seqsizes"], sizes)
+            assert bits(r["score"]) == bits(score)
+
+
+def test_path_pass_does_not_depend_on_call_history(engine, orc):
+    """The DP tables of the fast path pass live in an arena that is reused call after call:
+    every table cell the traceback reads (row 0 included) must have been written by THIS
+    call.  Tie-rich windows in changing subsets and orders over the same arena; a stale
+    row 0 shows as a different (equal-cost) path."""
+    rng = np.random.default_rng(47)
+    profs = [synth_profile(rng, int(K), 2.0, 0.05) for K in (3, 193, 256, 33, 65, 17, 4, 128, 15, 100, 63, 31)]
+    seqs = [random_seq(rng, int(rng.integers(5, 64))) for _ in profs]
+    engine.clear_profiles()
+    for p in profs:
+        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    engine.commit()
+    engine.set_sequences(seqs)
+    engine.set_mode(True, True)
+    smax = max(max(len(s) // 3, 1) for s in seqs)
+    table = np.zeros((smax + 1, 13), np.float32)
+    for s in range(1, smax + 1):
+        table[s] = synth_xt(orc, 3 * s, 1, 1, 2.0)
+    engine.set_xtrans_table(table)
+    want = []
+    for p, s in zip(profs, seqs):
+        _, xo, no = orc.path(p, synth_xt(orc, len(s), 1, 1, 2.0), s)
+        want.append(orc.unzip(p.K, len(s), xo, no))
+    n = len(profs)
+    orders = [list(range(n)), [8], list(range(n))[::-1], [7, 8], [8, 1], list(range(0, n, 2)), list(range(n))]
+    for it in range(6):
+        orders.append([int(i) for i in rng.permutation(n)[: int(rng.integers(1, n + 1))]])
+    for order in orders:
+        res = engine.path([(i, i, 0, len(seqs[i])) for i in order], trellis=False)
+        for i, r in zip(order, res):
+            assert np.array_equal(r["state_ids"], want[i][0]) and np.array_equal(r["seqsizes"], want[i][1]), (order, i)
+    engine.set_xtrans_table(np.zeros((0, 13), np.float32))
