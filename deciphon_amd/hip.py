@@ -209,6 +209,11 @@ class Engine:
     # ---- the DP ---------------------------------------------------------------
     @staticmethod
     def _windows(windows):
+        if isinstance(windows, np.ndarray):  # int32 [n][4] = (profile, seq, start, stop): no conversion
+            a = np.ascontiguousarray(windows, dtype=np.int32).reshape(-1, 4)
+            ptr = _p(a)
+            ptr._keep = a
+            return len(a), ptr
         n = len(windows)
         arr = (Window * max(n, 1))()
         for i, w in enumerate(windows):
