@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_ISSUE_PEAK = 256 * 4 * 2.4 / 4.0  # G wave64-VALU instr/s: 256 CUs x 4 SIMDs, 2.4 GHz, 4 cycles each
 BYTES_PER_CELL = 20.0  # five fp32 match-emission operands per DP cell (cost pass)
 SEED = 20250310
 
@@ -107,15 +108,16 @@ def cpu_baseline(db, reads, cores, budget_s=15.0):
 
 
 def measured_traffic():
-    """HBM bytes per step from the newest committed PMC summary (scripts/profile_bench.sh writes
-    profiles/*_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc passes)."""
+    """HBM bytes per step and VALU instructions per step from the newest committed PMC summary
+    (scripts/profile_bench.sh writes profiles/*_traffic.json: FETCH_SIZE / WRITE_SIZE / SQ_INSTS_*
+    collected in separate --pmc passes)."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
-        return None, None
+        return None, None, None
     t = json.load(open(files[-1]))
-    return t.get("hbm_bytes_per_step"), os.path.basename(files[-1])
+    return t.get("hbm_bytes_per_step"), os.path.basename(files[-1]), t.get("sq_insts_valu_per_step")
 
 
 def main():
@@ -194,7 +196,15 @@ def main():
         gcups = total_cells * args.steps / t_max / 1e9
         kernel_ms = ms / args.steps
         per_gpu_gbps = (cells * BYTES_PER_CELL) / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic()
+        traffic, traffic_src, valu_insts = measured_traffic()
+        # what actually binds: wave64 VALU instructions issue once per 4 cycles
+        # per SIMD -> 1024 SIMDs x 2.4 GHz / 4 = 614.4 G instr/s; counted instructions (PMC pass of the
+        # same workload) / measured kernel time of this run
+        issue = None
+        if valu_insts and args.reads == 1000 and args.read_len == 3000:
+            ach = valu_insts / (kernel_ms * 1e-3) / 1e9
+            issue = {"bound": "valu_issue", "achieved": ach, "peak": VALU_ISSUE_PEAK, "unit": "G wave-instr/s",
+                     "frac": ach / VALU_ISSUE_PEAK, "valu_insts_per_step": valu_insts}
         out = {
             "metric": "GCUPS (Viterbi DP cell updates/sec)", "value": gcups, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
@@ -208,7 +218,7 @@ def main():
                        "parallelism": f"reads sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": per_gpu_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": per_gpu_gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms_per_step": kernel_ms, "traffic_source": traffic_src,
+                         "kernel_ms_per_step": kernel_ms, "traffic_source": traffic_src, "issue": issue,
                          "note": "achieved = 20 B/cell (SURVEY 8d) x cells of one step / HIP-event time of one "
                                  "step on the engine's stream; operands are re-read from L2, so frac can exceed "
                                  "the HBM share (traffic = measured HBM bytes per step); the binding limit is "

@@ -55,6 +55,7 @@ import json
 import re
 
 fetch = write = 0.0
+insts = defaultdict(float)  # SQ_INSTS_* / GRBM_GUI_ACTIVE summed over the Viterbi kernels' dispatches
 steps = None
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -67,6 +68,8 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
                 fetch += float(r["Counter_Value"])
             if r["Counter_Name"] == "WRITE_SIZE":
                 write += float(r["Counter_Value"])
+            if r["Counter_Name"].startswith("SQ_INSTS_") or r["Counter_Name"] in ("GRBM_GUI_ACTIVE", "SQ_WAVES"):
+                insts[r["Counter_Name"]] += float(r["Counter_Value"])
         if per_kernel:
             steps = max(len(v) for v in per_kernel.values())
 if steps:
@@ -74,6 +77,8 @@ if steps:
     rec = {"fetch_kib_raw_per_step": fetch / steps, "write_kib_per_step": write / steps,
            "hbm_bytes_per_step": (2.0 * fetch + write) * 1024.0 / steps, "dispatches_per_kernel": steps,
            "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); separate --pmc passes"}
+    for k, v in sorted(insts.items()):  # wave-level instruction counts per step (bench.py: issue roofline)
+        rec[k.lower() + "_per_step"] = v / steps
     dst = os.path.join(out, tag + "_traffic.json")  # copy it to profiles/ to have bench.py report it
     json.dump(rec, open(dst, "w"), indent=1)
     print("== traffic ==", json.dumps(rec))
