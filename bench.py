@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_ISSUE_PEAK = 256 * 4 * 2.4 / 4.0  # G wave64-VALU instr/s: 256 CUs x 4 SIMDs, 2.4 GHz, 4 cycles each
+VALU_ISSUE_PEAK = 256 * 4 * 2.4 / 2.0  # G wave64-VALU instr/s: 256 CUs x 4 SIMD-32s, 2.4 GHz, 2 cycles each
 BYTES_PER_CELL = 20.0  # five fp32 match-emission operands per DP cell (cost pass)
 SEED = 20250310
 
@@ -197,8 +197,8 @@ def main():
         kernel_ms = ms / args.steps
         per_gpu_gbps = (cells * BYTES_PER_CELL) / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src, valu_insts = measured_traffic()
-        # what actually binds: wave64 VALU instructions issue once per 4 cycles
-        # per SIMD -> 1024 SIMDs x 2.4 GHz / 4 = 614.4 G instr/s; counted instructions (PMC pass of the
+        # what actually binds: a SIMD-32 takes 2 cycles per wave64 VALU
+        # instruction (MI355X_MICROARCH.md) -> 1024 SIMDs x 2.4 GHz / 2 = 1228.8 G instr/s; counted instructions (PMC pass of the
         # same workload) / measured kernel time of this run
         issue = None
         if valu_insts and args.reads == 1000 and args.read_len == 3000:
