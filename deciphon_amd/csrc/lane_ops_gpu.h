@@ -109,7 +109,7 @@ DCP_FN uint32_t read_laneu(lu x, int lane) { return (uint32_t)__builtin_amdgcn_r
 // visible by sync() (s_barrier) and consumed by the matching get_*().  A slot is
 // never re-published before every wave has passed a later sync(), so one buffer
 // per slot is enough.
-enum { GS_M, GS_I, GS_D, GS_E, GS_F, GS_X, GS_T0, GS_T1, GS_SLOTS };
+enum { GS_M, GS_I, GS_D, GS_E, GS_F, GS_X, GS_T0, GS_T1, GS_X0, GS_X1, GS_SLOTS };
 
 template <int W> struct Group;
 
@@ -122,6 +122,7 @@ template <> struct Group<1>
   DCP_FN void put_minu(int, lu) {}
   DCP_FN void put_lanes4(int, lf) {}
   DCP_FN void put_any(int, lm) {}
+  template <int Q> DCP_FN void put_tdd(lf const (&)[Q]) {}
   DCP_FN void put_count(int, lm) {}
   DCP_FN void sync() {}
   DCP_FN lf get_shift(int, lf x, float fill) { return lane_shift_up(x, fill); }
@@ -138,11 +139,17 @@ template <int W> struct Group
   lu lane;        // 0..64*W-1, position of this lane in the group
   int wave;       // wave index inside the workgroup (uniform)
   float *lds;     // [GS_SLOTS][16] words
+  float4 *rec;    // [2][16] per-row records {M, I, D of the wave's last position, min M}, by row parity
+  float *tdd;     // [16] sum of DD over each wave's positions but its first
   DCP_FN void init()
   {
     static_assert(W <= 16, "a workgroup holds at most 16 wavefronts");
     __shared__ float scratch[GS_SLOTS * 16];
+    __shared__ float4 records[2 * 16];
+    __shared__ float through[16];
     lds = scratch;
+    rec = records;
+    tdd = through;
     wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     lane = lane_ids() + (uint32_t)wave * 64u;
   }
@@ -176,6 +183,58 @@ template <int W> struct Group
     if (last_lane()) lds[slot * 16 + wave] = (float)c;
   }
   DCP_FN void sync() { __syncthreads(); }
+
+  // ---- one-barrier rows of the cost pass (viterbi_body.h, CostWave::row) ----
+  DCP_FN lf seg_shift_up(lf x, lf fill) // wave_shr:1, the wave's first lane takes `fill`
+  {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
+  }
+  DCP_FN bool seg_any(lm m) const { return wave_any(m); }
+  DCP_FN lm seg_first() const { return (lane & 63u) == 0u; }
+  template <int Q> DCP_FN void put_tdd(lf const (&DD)[Q])
+  {
+    float t = seg_first() ? 0.0f : DD[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q) t += DD[q];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+    if (last_lane()) tdd[wave] = t;
+    __syncthreads();
+  }
+  DCP_FN void put_rec(int par, lf m_last, lf i_last, lf d_last, lf m_all)
+  {
+    float const e = wave_min(m_all);
+    if (last_lane()) rec[par * 16 + wave] = make_float4(m_last, i_last, d_last, e);
+  }
+  DCP_FN float rec_min_e(int par) const
+  {
+    float m = rec[par * 16].w;
+#pragma unroll
+    for (int w = 1; w < W; ++w) m = __builtin_fminf(m, rec[par * 16 + w].w);
+    return m;
+  }
+  DCP_FN lf prev_rec(int par, int field) const // of the previous wave; +inf before the first
+  {
+    if (wave == 0) return __builtin_inff();
+    float const *r = reinterpret_cast<float const *>(rec + par * 16 + wave - 1);
+    return r[field];
+  }
+  // could anything entering a wave at its first lane still lower the D it published?
+  DCP_FN bool rec_could_change(int par, float E) const
+  {
+    bool any = false;
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+    {
+      float const s = E + tdd[w];
+      float const bound = __builtin_fminf(s * 0.9999f, s * 1.0001f);
+      any = any || bound < rec[par * 16 + w].z;
+    }
+    return any;
+  }
+  DCP_FN void note_fallback() const {}
+
   DCP_FN lf get_shift(int slot, lf x, float fill)
   {
     float const prev = wave > 0 ? lds[slot * 16 + wave - 1] : fill;

@@ -104,6 +104,7 @@ template <int Q, int W, bool STORE = false> struct CostWave
     EBv = lf_pin(xt[DCP_EB]);
     JBv = lf_pin(xt[DCP_JB]);
     shM = shI = shD = lf_splat(DCP_INF);
+    g.put_tdd(DD); // W > 1: what running through a whole wave of delete states costs (row())
     ET = xt[DCP_ET];
     CT = xt[DCP_CT];
     RR = xt[DCP_RR];
@@ -138,7 +139,7 @@ template <int Q, int W, bool STORE = false> struct CostWave
 
   template <int P> DCP_FN void row(int l, int L)
   {
-    lf M[Q], I[Q], D[Q];
+    lf M[Q], I[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {
@@ -158,44 +159,128 @@ template <int Q, int W, bool STORE = false> struct CostWave
     lf m = M[0];
 #pragma unroll
     for (int q = 1; q < Q; ++q) m = lmin(m, M[q]);
-    // what crosses a wave boundary (nothing to publish when the group is one wave)
-    g.put_last(GS_M, M[Q - 1]);
-    g.put_last(GS_I, I[Q - 1]);
-    g.put_min(GS_E, m);
-    g.put_lanes4(GS_X, X);
-    g.sync();
-    lf const Msh0 = g.get_shift_keep(GS_M, M[Q - 1], shM);
-    lf const Ish0 = g.get_shift_keep(GS_I, I[Q - 1], shI);
-    E = g.get_min(GS_E, m);
-    float const N = g.get_lane(GS_X, X, 0);
-    float const J = g.get_lane(GS_X, X, 1);
-    lf const B = lmin3(N + NBv, E + EBv, J + JBv); // c-core/viterbi.c:495-496,582-583 (uniform)
-
-    // D_l[k] = min(M_l[k-1] + MD[k], D_l[k-1] + DD[k])  (c-core/viterbi.c:538,553-580):
-    // serial inside a lane, then carried across lanes until no lane improves (the
-    // reference's lazy D->D loop, c-core/viterbi.c:569-580)
-    D[0] = Msh0 + MD[0];
-#pragma unroll
-    for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
-    g.put_last(GS_D, D[Q - 1]);
-    g.sync();
-    lf Dsh0 = g.get_shift_keep(GS_D, D[Q - 1], shD);
-    lf x = Dsh0 + DD[0];
-    lm better = llt(x, D[0]);
-    g.put_any(GS_F, better);
-    g.sync();
-    while (g.get_any(GS_F, better)) // one more lane boundary per turn; a few turns per row on real data
+    lf D[Q];
+    lf Msh0, Ish0, Dsh0, B;
+    float N, J;
+    if constexpr (W == 1)
     {
-      D[0] = lmin(D[0], x);
+      Msh0 = lane_shift_up_keep(M[Q - 1], shM);
+      Ish0 = lane_shift_up_keep(I[Q - 1], shI);
+      E = wave_min(m);
+      N = read_lane(X, 0);
+      J = read_lane(X, 1);
+      B = lmin3(N + NBv, E + EBv, J + JBv); // c-core/viterbi.c:495-496,582-583 (uniform)
+
+      // D_l[k] = min(M_l[k-1] + MD[k], D_l[k-1] + DD[k])  (c-core/viterbi.c:538,553-580):
+      // serial inside a lane, then carried across lanes until no lane improves (the
+      // reference's lazy D->D loop, c-core/viterbi.c:569-580)
+      D[0] = Msh0 + MD[0];
 #pragma unroll
-      for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
-      g.put_last(GS_D, D[Q - 1]);
-      g.sync();
-      Dsh0 = g.get_shift_keep(GS_D, D[Q - 1], shD);
-      x = Dsh0 + DD[0];
+      for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
+      Dsh0 = lane_shift_up_keep(D[Q - 1], shD);
+      lf x = Dsh0 + DD[0];
+      lm better = llt(x, D[0]);
+      while (wave_any(better)) // one more lane boundary per turn; a few turns per row on real data
+      {
+        D[0] = lmin(D[0], x);
+#pragma unroll
+        for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+        Dsh0 = lane_shift_up_keep(D[Q - 1], shD);
+        x = Dsh0 + DD[0];
+        better = llt(x, D[0]);
+      }
+    }
+    else
+    {
+      // W wavefronts, ONE barrier per row.  Before it every wave finishes what it can alone:
+      // its D chain with nothing entering at its first lane.  It publishes one record
+      // {M, I, D of its last position, min of its M}; after the barrier the first lane of
+      // each wave takes M, I, D of the previous wave's last position as its k-1 neighbour.
+      // That is exact provided the D published by every wave is already final, i.e. nothing
+      // entering a wave at its first lane can run through ALL its positions and still arrive
+      // below the published value.  Whatever enters costs at least E (it is some M of this row
+      // plus non-negative costs) and running through wave w adds tdd(w) = sum of DD over its
+      // positions but the first, so  E + tdd(w) >= D_last(w)  for every w (with a margin for the
+      // order of the fp32 additions) proves it -- every wave evaluates the same test on the
+      // same records.  If it fails (profiles whose delete runs are nearly free) the row falls
+      // back to the exchange-until-stable protocol below, barriers and all.
+      int const par = l & 1;
+      lf const inf = lf_splat(DCP_INF);
+      lf x, Dsh;
+      lm better;
+      D[0] = g.seg_shift_up(M[Q - 1], inf) + MD[0];
+#pragma unroll
+      for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
+      Dsh = g.seg_shift_up(D[Q - 1], inf);
+      x = Dsh + DD[0];
       better = llt(x, D[0]);
-      g.put_any(GS_F, better);
+      while (g.seg_any(better))
+      {
+        D[0] = lmin(D[0], x);
+#pragma unroll
+        for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+        Dsh = g.seg_shift_up(D[Q - 1], inf);
+        x = Dsh + DD[0];
+        better = llt(x, D[0]);
+      }
+      g.put_rec(par, M[Q - 1], I[Q - 1], D[Q - 1], m);
+      g.put_lanes4(GS_X0 + par, X);
       g.sync();
+      E = g.rec_min_e(par);
+      lf const Mp = g.prev_rec(par, 0), Ip = g.prev_rec(par, 1);
+      Msh0 = g.seg_shift_up(M[Q - 1], Mp);
+      Ish0 = g.seg_shift_up(I[Q - 1], Ip);
+      N = g.get_lane(GS_X0 + par, X, 0);
+      J = g.get_lane(GS_X0 + par, X, 1);
+      B = lmin3(N + NBv, E + EBv, J + JBv);
+      if (!g.rec_could_change(par, E))
+      {
+        lf const Dp = g.prev_rec(par, 2);
+        // the first lane of each wave: D[0] = min(M[k-1] + MD, D[k-1] + DD) with the neighbour's
+        // values; then on through the wave while it improves anything
+        D[0] = lsel(g.seg_first(), lmin(Mp + MD[0], Dp + DD[0]), D[0]);
+#pragma unroll
+        for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+        Dsh0 = g.seg_shift_up(D[Q - 1], Dp);
+        x = Dsh0 + DD[0];
+        better = llt(x, D[0]);
+        while (g.seg_any(better))
+        {
+          D[0] = lmin(D[0], x);
+#pragma unroll
+          for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+          Dsh0 = g.seg_shift_up(D[Q - 1], Dp);
+          x = Dsh0 + DD[0];
+          better = llt(x, D[0]);
+        }
+      }
+      else
+      {
+        g.note_fallback();
+        D[0] = Msh0 + MD[0];
+#pragma unroll
+        for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
+        g.put_last(GS_D, D[Q - 1]);
+        g.sync();
+        Dsh0 = g.get_shift(GS_D, D[Q - 1], DCP_INF);
+        x = Dsh0 + DD[0];
+        better = llt(x, D[0]);
+        g.put_any(GS_F, better);
+        g.sync();
+        while (g.get_any(GS_F, better))
+        {
+          D[0] = lmin(D[0], x);
+#pragma unroll
+          for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+          g.put_last(GS_D, D[Q - 1]);
+          g.sync();
+          Dsh0 = g.get_shift(GS_D, D[Q - 1], DCP_INF);
+          x = Dsh0 + DD[0];
+          better = llt(x, D[0]);
+          g.put_any(GS_F, better);
+          g.sync();
+        }
+      }
     }
 
     // fold row l into the ring (slot P held row l-5, no longer needed)
@@ -215,7 +300,7 @@ template <int Q, int W, bool STORE = false> struct CostWave
       store_q<Q>(row, g.lane, M);
       store_q<Q>(row + tabKp, g.lane, I);
       store_q<Q>(row + 2 * tabKp, g.lane, D);
-      float const C = g.get_lane(GS_X, X, 2);
+      float const C = g.get_lane(GS_X0 + (l & 1), X, 2);
       store_sp_lane0(tab_sp + (size_t)l * DCP_SP_STRIDE, g.lane, lf_splat(N), B, lf_splat(J), lf_splat(E), lf_splat(C));
     }
   }

@@ -100,3 +100,11 @@ extern "C" int emul_traceback(float const *pool, DcpProfileDev const *pf, DcpCod
   in.xt = xt;
   return dcp_traceback(in, buf, cap);
 }
+
+// rows of multi-wave cost passes that left the one-barrier protocol since the last call
+extern "C" long emul_fallback_rows(void)
+{
+  long const n = em_fallback_rows;
+  em_fallback_rows = 0;
+  return n;
+}

@@ -72,7 +72,10 @@ inline uint64_t wave_ballot(lm m) { uint64_t b = 0; EM_FOR if (m.v[i_]) b |= 1ul
 inline float read_lane(lf x, int lane) { return x.v[lane]; }
 inline uint32_t read_laneu(lu x, int lane) { return x.v[lane]; }
 
-enum { GS_M, GS_I, GS_D, GS_E, GS_F, GS_X, GS_T0, GS_T1, GS_SLOTS };
+enum { GS_M, GS_I, GS_D, GS_E, GS_F, GS_X, GS_T0, GS_T1, GS_X0, GS_X1, GS_SLOTS };
+
+// rows of the cost pass that took the exchange-until-stable fallback (tests read and reset it)
+static thread_local long em_fallback_rows = 0;
 
 template <int W> struct Group
 {
@@ -82,6 +85,68 @@ template <int W> struct Group
     em_lanes = 64 * W;
     lane = lane_ids();
   }
+  // ---- one-barrier rows: here the W waves are real 64-lane segments of the vector ----
+  struct Rec { float m, i, d, e; };
+  Rec rec[2][16];
+  float tdd[16];
+  lf seg_shift_up(lf x, lf fill)
+  {
+    lf r;
+    for (int i = 0; i < em_lanes; ++i) r.v[i] = (i % 64 == 0) ? fill.v[i] : x.v[i - 1];
+    return r;
+  }
+  bool seg_any(lm m) { return wave_any(m); } // extra turns in a converged wave change nothing
+  lm seg_first() { lm r; EM_FOR r.v[i_] = (i_ % 64) == 0; return r; }
+  template <int Q> void put_tdd(lf const (&DD)[Q])
+  {
+    for (int w = 0; w < W; ++w)
+    {
+      float t = 0.0f;
+      for (int i = 64 * w; i < 64 * w + 64; ++i)
+        for (int q = 0; q < Q; ++q)
+          if (!(i == 64 * w && q == 0)) t += DD[q].v[i];
+      tdd[w] = t;
+    }
+  }
+  void put_rec(int par, lf m_last, lf i_last, lf d_last, lf m_all)
+  {
+    for (int w = 0; w < W; ++w)
+    {
+      float e = m_all.v[64 * w];
+      for (int i = 64 * w; i < 64 * w + 64; ++i) e = fminf(e, m_all.v[i]);
+      rec[par][w] = Rec{m_last.v[64 * w + 63], i_last.v[64 * w + 63], d_last.v[64 * w + 63], e};
+    }
+  }
+  float rec_min_e(int par)
+  {
+    float m = rec[par][0].e;
+    for (int w = 1; w < W; ++w) m = fminf(m, rec[par][w].e);
+    return m;
+  }
+  lf prev_rec(int par, int field)
+  {
+    lf r;
+    for (int i = 0; i < em_lanes; ++i)
+    {
+      int const w = i / 64;
+      Rec const &p = rec[par][w > 0 ? w - 1 : 0];
+      r.v[i] = w == 0 ? INFINITY : field == 0 ? p.m : field == 1 ? p.i : p.d;
+    }
+    return r;
+  }
+  bool rec_could_change(int par, float E)
+  {
+    bool any = false;
+    for (int w = 0; w < W; ++w)
+    {
+      float const s = E + tdd[w];
+      float const bound = fminf(s * 0.9999f, s * 1.0001f);
+      any = any || bound < rec[par][w].d;
+    }
+    return any;
+  }
+  void note_fallback() { ++em_fallback_rows; }
+
   void put_last(int, lf) {}
   void put_min(int, lf) {}
   void put_minu(int, lu) {}
