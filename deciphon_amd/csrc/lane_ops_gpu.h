@@ -139,17 +139,20 @@ template <int W> struct Group
   lu lane;        // 0..64*W-1, position of this lane in the group
   int wave;       // wave index inside the workgroup (uniform)
   float *lds;     // [GS_SLOTS][16] words
-  float4 *rec;    // [2][16] per-row records {M, I, D of the wave's last position, min M}, by row parity
+  float4 *rec;    // [2][17] per-row records {M, I, D of the wave's last position, min M} by row parity;
+                  // entry 0 = all +inf (the neighbour of wave 0), wave w at entry w + 1
   float *tdd;     // [16] sum of DD over each wave's positions but its first
+  float tddv[W <= 8 ? W : 1]; // the same in registers (W <= 8)
   DCP_FN void init()
   {
     static_assert(W <= 16, "a workgroup holds at most 16 wavefronts");
     __shared__ float scratch[GS_SLOTS * 16];
-    __shared__ float4 records[2 * 16];
+    __shared__ float4 records[2 * 17];
     __shared__ float through[16];
     lds = scratch;
     rec = records;
     tdd = through;
+    if (threadIdx.x < 2) records[threadIdx.x * 17] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());
     wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     lane = lane_ids() + (uint32_t)wave * 64u;
   }
@@ -200,38 +203,76 @@ template <int W> struct Group
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
     if (last_lane()) tdd[wave] = t;
-    __syncthreads();
+    __syncthreads(); // also publishes the +inf record of init()
+    if constexpr (W <= 8)
+    {
+#pragma unroll
+      for (int w = 0; w < W; ++w) tddv[w] = tdd[w];
+    }
   }
   DCP_FN void put_rec(int par, lf m_last, lf i_last, lf d_last, lf m_all)
   {
     float const e = wave_min(m_all);
-    if (last_lane()) rec[par * 16 + wave] = make_float4(m_last, i_last, d_last, e);
+    if (last_lane()) rec[par * 17 + wave + 1] = make_float4(m_last, i_last, d_last, e);
   }
-  DCP_FN float rec_min_e(int par) const
+  // the previous wave's record (one b128 read; +inf before the first wave)
+  DCP_FN void get_prev(int par, lf &Mp, lf &Ip, lf &Dp) const
   {
-    float m = rec[par * 16].w;
-#pragma unroll
-    for (int w = 1; w < W; ++w) m = __builtin_fminf(m, rec[par * 16 + w].w);
-    return m;
+    float4 const r = rec[par * 17 + wave];
+    Mp = r.x;
+    Ip = r.y;
+    Dp = r.z;
   }
-  DCP_FN lf prev_rec(int par, int field) const // of the previous wave; +inf before the first
+  // E = min over the waves' minima; could anything entering a wave at its first lane still
+  // lower the D it published?  (one b64 read per wave)
+  DCP_FN void get_e_could(int par, float &E, bool &could) const
   {
-    if (wave == 0) return __builtin_inff();
-    float const *r = reinterpret_cast<float const *>(rec + par * 16 + wave - 1);
-    return r[field];
-  }
-  // could anything entering a wave at its first lane still lower the D it published?
-  DCP_FN bool rec_could_change(int par, float E) const
-  {
-    bool any = false;
-#pragma unroll
-    for (int w = 0; w < W; ++w)
+    float const *r = reinterpret_cast<float const *>(rec + par * 17 + 1);
+    if constexpr (W <= 8)
     {
-      float const s = E + tdd[w];
-      float const bound = __builtin_fminf(s * 0.9999f, s * 1.0001f);
-      any = any || bound < rec[par * 16 + w].z;
+      float d[W], e[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+      {
+        float2 const de = *reinterpret_cast<float2 const *>(r + 4 * w + 2);
+        d[w] = de.x;
+        e[w] = de.y;
+      }
+      float m = e[0];
+#pragma unroll
+      for (int w = 1; w < W; ++w) m = __builtin_fminf(m, e[w]);
+      bool any = false;
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+      {
+        float const s = m + tddv[w];
+        any = any || __builtin_fminf(s * 0.9999f, s * 1.0001f) < d[w];
+      }
+      E = m;
+      could = any;
     }
-    return any;
+    else // 1024-thread workgroups are capped at 128 VGPRs: two passes over LDS instead of 2W registers
+    {
+      float m = r[3];
+#pragma unroll
+      for (int w = 1; w < W; ++w) m = __builtin_fminf(m, r[4 * w + 3]);
+      bool any = false;
+#pragma unroll
+      for (int w = 0; w < W; ++w)
+      {
+        float const s = m + tdd[w];
+        any = any || __builtin_fminf(s * 0.9999f, s * 1.0001f) < r[4 * w + 2];
+      }
+      E = m;
+      could = any;
+    }
+  }
+  // N and J of the special states (lanes 0, 1 of wave 0's X), one b64 read
+  DCP_FN void get_nj(int slot, lf, float &N, float &J) const
+  {
+    float2 const v = *reinterpret_cast<float2 const *>(lds + slot * 16);
+    N = v.x;
+    J = v.y;
   }
   DCP_FN void note_fallback() const {}
 

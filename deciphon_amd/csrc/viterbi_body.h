@@ -226,16 +226,16 @@ template <int Q, int W, bool STORE = false> struct CostWave
       g.put_rec(par, M[Q - 1], I[Q - 1], D[Q - 1], m);
       g.put_lanes4(GS_X0 + par, X);
       g.sync();
-      E = g.rec_min_e(par);
-      lf const Mp = g.prev_rec(par, 0), Ip = g.prev_rec(par, 1);
+      lf Mp, Ip, Dp;
+      bool could;
+      g.get_prev(par, Mp, Ip, Dp);
+      g.get_e_could(par, E, could);
+      g.get_nj(GS_X0 + par, X, N, J);
       Msh0 = g.seg_shift_up(M[Q - 1], Mp);
       Ish0 = g.seg_shift_up(I[Q - 1], Ip);
-      N = g.get_lane(GS_X0 + par, X, 0);
-      J = g.get_lane(GS_X0 + par, X, 1);
       B = lmin3(N + NBv, E + EBv, J + JBv);
-      if (!g.rec_could_change(par, E))
+      if (!could)
       {
-        lf const Dp = g.prev_rec(par, 2);
         // the first lane of each wave: D[0] = min(M[k-1] + MD, D[k-1] + DD) with the neighbour's
         // values; then on through the wave while it improves anything
         D[0] = lsel(g.seg_first(), lmin(Mp + MD[0], Dp + DD[0]), D[0]);

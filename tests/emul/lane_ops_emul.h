@@ -117,33 +117,35 @@ template <int W> struct Group
       rec[par][w] = Rec{m_last.v[64 * w + 63], i_last.v[64 * w + 63], d_last.v[64 * w + 63], e};
     }
   }
-  float rec_min_e(int par)
+  void get_prev(int par, lf &Mp, lf &Ip, lf &Dp)
   {
-    float m = rec[par][0].e;
-    for (int w = 1; w < W; ++w) m = fminf(m, rec[par][w].e);
-    return m;
-  }
-  lf prev_rec(int par, int field)
-  {
-    lf r;
     for (int i = 0; i < em_lanes; ++i)
     {
       int const w = i / 64;
       Rec const &p = rec[par][w > 0 ? w - 1 : 0];
-      r.v[i] = w == 0 ? INFINITY : field == 0 ? p.m : field == 1 ? p.i : p.d;
+      Mp.v[i] = w == 0 ? INFINITY : p.m;
+      Ip.v[i] = w == 0 ? INFINITY : p.i;
+      Dp.v[i] = w == 0 ? INFINITY : p.d;
     }
-    return r;
   }
-  bool rec_could_change(int par, float E)
+  void get_e_could(int par, float &E, bool &could)
   {
+    float m = rec[par][0].e;
+    for (int w = 1; w < W; ++w) m = fminf(m, rec[par][w].e);
     bool any = false;
     for (int w = 0; w < W; ++w)
     {
-      float const s = E + tdd[w];
+      float const s = m + tdd[w];
       float const bound = fminf(s * 0.9999f, s * 1.0001f);
       any = any || bound < rec[par][w].d;
     }
-    return any;
+    E = m;
+    could = any;
+  }
+  void get_nj(int, lf X, float &N, float &J)
+  {
+    N = X.v[0];
+    J = X.v[1];
   }
   void note_fallback() { ++em_fallback_rows; }
 
