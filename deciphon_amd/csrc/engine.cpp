@@ -174,6 +174,7 @@ struct dcp_hip
   // problems / results
   DevBuf<DcpProblem> d_problems;
   DevBuf<float> d_out;
+  DevBuf<float> d_ring;            // strip class (K > 4096): the rings of folded rows, one per workgroup in flight
   TableArena tables;               // DP tables of the fast path pass
   std::vector<int64_t> table_addr; // per window of the slice being staged (device addresses)
   std::vector<int> path_order;     // fast path pass: request windows, slowest first
@@ -294,6 +295,8 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
   }
   st.c_begin[DCP_NUM_CLASSES] = i;
   if (i != n) return fail(x, DCP_ELARGECORESIZE, "profile outside every kernel class");
+  if (st.c_begin[DCP_STRIP_CLASS + 1] > st.c_begin[DCP_STRIP_CLASS])
+    HIP_TRY(x, x->d_ring.reserve((size_t)DCP_RING_SLOTS * DCP_RING_FLOATS), DCP_ENOMEM);
   int rc = ensure_xt(x, max_s + 1);
   if (rc) return rc;
   x->staged_n = -1; // the device problem list is about to be replaced
@@ -317,6 +320,7 @@ DcpLaunch launch_args(dcp_hip *x, Staged const &st, int c)
   a.arena = x->d_trellis.p;
   a.nprob = st.c_begin[c + 1] - st.c_begin[c];
   a.stream = x->stream;
+  a.ring = x->d_ring.p;
   return a;
 }
 
@@ -436,11 +440,12 @@ static int describe(dcp_hip *x, int K, char const *accession, HostProfile &hp)
 {
   if (K < 1 || K > DCP_MODEL_MAX) return fail(x, DCP_ELARGECORESIZE, "core size out of range");
   int const cls = dcp_class_of(K);
-  if (cls < 0) return fail(x, DCP_ELARGECORESIZE, "core size beyond DCP_MAX_CORE_SIZE (4096) is not supported yet");
+  if (cls < 0) return fail(x, DCP_ELARGECORESIZE, "core size beyond DCP_MAX_CORE_SIZE (16383: state ids keep 14 bits for k + 1)");
   hp.K = K;
   hp.cls = cls;
   dcp_class_shape(cls, &hp.Q, &hp.W);
   hp.Kp = 64 * hp.Q * hp.W;
+  if (cls == DCP_STRIP_CLASS) hp.Kp *= (K + hp.Kp - 1) / hp.Kp; // whole strips
   hp.pool_off = 0;
   hp.accession = accession ? accession : "";
   return 0;
@@ -949,6 +954,11 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
   if (n == 0) return 0;
   std::vector<dcp_hip_window> w((size_t)n);
   for (int j = 0; j < n; ++j) w[(size_t)j] = x->path_wins[(size_t)idx[(size_t)j]];
+  for (dcp_hip_window const &v : w)
+    if (x->profiles[(size_t)v.profile].cls == DCP_STRIP_CLASS)
+      return fail(x, DCP_ELARGECORESIZE,
+                  "the pass-by-pass path kernel (exact fp32 ties, packed trellis) stops at core size 4096; "
+                  "longer profiles have scores and tie-free paths only");
   Staged st;
   int rc = stage(x, n, w.data(), ARENA_TRELLIS, st);
   if (rc) return rc;

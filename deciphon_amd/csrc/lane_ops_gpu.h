@@ -148,7 +148,7 @@ template <int W> struct Group
     static_assert(W <= 16, "a workgroup holds at most 16 wavefronts");
     __shared__ float scratch[GS_SLOTS * 16];
     __shared__ float4 records[2 * 17];
-    __shared__ float through[16];
+    __shared__ float through[16 + DCP_MAX_STRIPS * 16]; // [16] of CostWave, then [strip][16] of StripWave
     lds = scratch;
     rec = records;
     tdd = through;
@@ -267,6 +267,46 @@ template <int W> struct Group
       could = any;
     }
   }
+  // ---- StripWave (K > 4096): the same exchange with the previous strip in front of wave 0 ----
+  template <int Q> DCP_FN void put_tdd_strip(int s, lf const (&DD)[Q])
+  {
+    float t = seg_first() ? 0.0f : DD[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q) t += DD[q];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+    if (last_lane()) tdd[16 + s * 16 + wave] = t;
+  }
+  DCP_FN void put_carry(int par, lf m, lf i, lf d)
+  {
+    if (wave == W - 1 && last_lane()) rec[par * 17] = make_float4(m, i, d, __builtin_inff());
+  }
+  DCP_FN void put_carry_inf(int par)
+  {
+    float const inf = __builtin_inff();
+    if (wave == W - 1 && last_lane()) rec[par * 17] = make_float4(inf, inf, inf, inf);
+  }
+  // E of this strip; could anything entering a wave at its first lane (it costs at least
+  // min(floor_e, E)) still lower the D that wave published?
+  DCP_FN void get_e_could_row(int par, int s, float floor_e, float &E, bool &could) const
+  {
+    float const *r = reinterpret_cast<float const *>(rec + par * 17 + 1);
+    float m = r[3];
+#pragma unroll
+    for (int w = 1; w < W; ++w) m = __builtin_fminf(m, r[4 * w + 3]);
+    float const lo = __builtin_fminf(m, floor_e);
+    bool any = false;
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+    {
+      float const v = lo + tdd[16 + s * 16 + w];
+      any = any || __builtin_fminf(v * 0.9999f, v * 1.0001f) < r[4 * w + 2];
+    }
+    E = m;
+    could = any;
+  }
+  DCP_FN lf get_shift_carry(int slot, lf x, lf fill) { return get_shift(slot, x, fill); }
+
   // N and J of the special states (lanes 0, 1 of wave 0's X), one b64 read
   DCP_FN void get_nj(int slot, lf, float &N, float &J) const
   {

@@ -351,6 +351,289 @@ template <int Q, int W, bool STORE = false> struct CostWave
 };
 
 // =============================================================================
+// Scores of profiles too long for the registers of one workgroup (K > 4096).
+// The same recurrences as CostWave, strip by strip: a strip is KS = 64*Q*W positions, the
+// workgroup walks the S = Kp/KS strips of a row left to right, and what CostWave keeps in
+// registers lives in HBM/L2 between visits:
+//   ring[0][z][k] = rest_z[k] = min(M_z[k-1]+MM[k], I_z[k-1]+IM[k], D_z[k-1]+DM[k])
+//   ring[1][z][k] = Ipre_z[k]                       (z = row % 5, five rows back)
+// The B term of Mpre_z[k] = min(B_z + BM[k], rest_z[k]) cannot be folded in when row z is
+// finished strip by strip -- B_z needs E_z = min over ALL strips -- so it is applied when the
+// row is used: M_l[k] = min_t(min(B_{l-t} + BM[k], rest_{l-t}[k]) + match[c_t][k]), the same
+// fp32 values.  k-1 across a strip boundary and the D chain entering a strip come from the
+// previous strip of the same row, which is complete: its last position is "the record of the
+// wave before wave 0" of the one-barrier exchange (CostWave::row).
+// =============================================================================
+template <int Q, int W, bool STORE = false> struct StripWave
+{
+  Group<W> g;
+  float *__restrict__ tab_cells = nullptr; // [(L+1)][3][Kp]
+  float *__restrict__ tab_sp = nullptr;    // [(L+1)][DCP_SP_STRIDE]
+  float *__restrict__ ring = nullptr;      // [2][5][Kp]
+  float const *__restrict__ trans = nullptr;
+  int Kp = 0, S = 0;
+  lf Spre[5];
+  lf sa, sb, X;
+  float Bz[5]; // B of the five previous rows, by ring slot
+  float NB, EB, JB, ET, CT, RR, E;
+  RowSrc rows;
+  lu voff;
+  uint32_t stride_bytes;
+  DcpCodeRow const *__restrict__ codes;
+  int tick = 0; // parity of the next exchange
+
+  enum { KS = 64 * Q * W };
+
+  DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, DcpCodeRow const *__restrict__ code_rows,
+                   float const *__restrict__ xt)
+  {
+    g.init();
+    lu const lane = g.lane;
+    Kp = pf.Kp;
+    S = Kp / KS;
+    stride_bytes = (uint32_t)(Kp + DCP_ROW_HDR) * 4u;
+    rows = rowsrc_make(pool + pf.rows_off, (uint32_t)DCP_TABLE_SIZE * stride_bytes);
+    voff = row_lane_offset<Q>(lane);
+    codes = code_rows;
+    trans = pool + pf.trans_off;
+    NB = xt[DCP_NB];
+    EB = xt[DCP_EB];
+    JB = xt[DCP_JB];
+    ET = xt[DCP_ET];
+    CT = xt[DCP_CT];
+    RR = xt[DCP_RR];
+    float const SN = xt[DCP_SN], SB = xt[DCP_SB];
+    lm const l0 = lequ(lane, lu_splat(0)), l1 = lequ(lane, lu_splat(1));
+    lm const l2 = lequ(lane, lu_splat(2)), l3 = lequ(lane, lu_splat(3));
+    lf const inf = lf_splat(DCP_INF);
+    sa = lsel(l1, lf_splat(xt[DCP_EJ]), lsel(l2, lf_splat(xt[DCP_EC]), inf));
+    sb = lsel(l0, lf_splat(xt[DCP_NN]),
+              lsel(l1, lf_splat(xt[DCP_JJ]), lsel(l2, lf_splat(xt[DCP_CC]), lsel(l3, lf_splat(RR), inf))));
+#pragma unroll
+    for (int z = 0; z < 5; ++z)
+    {
+      Spre[z] = inf;
+      Bz[z] = DCP_INF;
+    }
+    Bz[0] = SB; // row 0: B = S + SB, everything else +inf (c-core/viterbi.c:471-473)
+    Spre[0] = lsel(l0, lf_splat(0.0f + SN), lsel(l3, lf_splat(-RR + RR), inf));
+    X = lsel(l3, lf_splat(-RR), inf);
+    E = DCP_INF;
+    lf infq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) infq[q] = inf;
+    for (int s = 0; s < S; ++s)
+    {
+      lf DD[Q];
+      load_q<Q>(trans + (size_t)DCP_DD * Kp + (size_t)s * KS, lane, DD);
+      g.put_tdd_strip(s, DD); // what running through a whole wave of this strip's delete states costs
+      for (int z = 0; z < 10; ++z) store_q<Q>(ring + (size_t)z * Kp + (size_t)s * KS, lane, infq);
+      if (STORE)
+        for (int z = 0; z < 3; ++z) store_q<Q>(tab_cells + (size_t)z * Kp + (size_t)s * KS, lane, infq);
+    }
+    if (STORE) store_sp_lane0(tab_sp, lane, inf, lf_splat(SB), inf, inf, inf);
+    g.put_carry_inf(0);
+    g.put_carry_inf(1);
+    g.sync();
+  }
+
+  template <int P> DCP_FN void row(int l)
+  {
+    lu const lane = g.lane;
+    lf const inf = lf_splat(DCP_INF);
+    DcpCodeRow const cr = codes[l];
+    uint32_t off[5];
+    float nil[5], bgv[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+    {
+      off[t] = cr.c[t] * stride_bytes;
+      load_row_hdr(rows, off[t], nil[t], bgv[t]);
+    }
+    X = lmin3(lmin3(Spre[DCP_SL(P, 5)] + nil[4], Spre[DCP_SL(P, 4)] + nil[3], Spre[DCP_SL(P, 3)] + nil[2]),
+              Spre[DCP_SL(P, 2)] + nil[1], Spre[DCP_SL(P, 1)] + nil[0]);
+    g.put_lanes4(GS_X0 + (l & 1), X); // visible after this row's first exchange
+    float Erun = DCP_INF;
+    for (int s = 0; s < S; ++s)
+    {
+      size_t const col = (size_t)s * KS;
+      lf BM[Q], MM[Q], MI[Q], MD[Q], IM[Q], II[Q], DM[Q], DD[Q];
+      load_q<Q>(trans + (size_t)DCP_BM * Kp + col, lane, BM);
+      load_q<Q>(trans + (size_t)DCP_MM * Kp + col, lane, MM);
+      load_q<Q>(trans + (size_t)DCP_MI * Kp + col, lane, MI);
+      load_q<Q>(trans + (size_t)DCP_MD * Kp + col, lane, MD);
+      load_q<Q>(trans + (size_t)DCP_IM * Kp + col, lane, IM);
+      load_q<Q>(trans + (size_t)DCP_II * Kp + col, lane, II);
+      load_q<Q>(trans + (size_t)DCP_DM * Kp + col, lane, DM);
+      load_q<Q>(trans + (size_t)DCP_DD * Kp + col, lane, DD);
+      lf M[Q], I[Q], D[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) M[q] = I[q] = inf;
+#pragma unroll
+      for (int t = 5; t >= 1; --t)
+      {
+        lf r[Q], ip[Q], em[Q];
+        load_q<Q>(ring + (size_t)DCP_SL(P, t) * Kp + col, lane, r);
+        load_q<Q>(ring + (size_t)(5 + DCP_SL(P, t)) * Kp + col, lane, ip);
+        load_row_q<Q>(rows, voff + (uint32_t)(col * 4), off[t - 1], em);
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+        {
+          M[q] = lmin(M[q], lmin(Bz[DCP_SL(P, t)] + BM[q], r[q]) + em[q]);
+          I[q] = lmin(I[q], ip[q] + bgv[t - 1]);
+        }
+      }
+      lf m = M[0];
+#pragma unroll
+      for (int q = 1; q < Q; ++q) m = lmin(m, M[q]);
+
+      // the one-barrier exchange of CostWave::row, with the previous strip's last position
+      // standing in front of wave 0
+      int const par = tick;
+      tick ^= 1;
+      lf x, Dsh;
+      lm better;
+      D[0] = g.seg_shift_up(M[Q - 1], inf) + MD[0];
+#pragma unroll
+      for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
+      Dsh = g.seg_shift_up(D[Q - 1], inf);
+      x = Dsh + DD[0];
+      better = llt(x, D[0]);
+      while (g.seg_any(better))
+      {
+        D[0] = lmin(D[0], x);
+#pragma unroll
+        for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+        Dsh = g.seg_shift_up(D[Q - 1], inf);
+        x = Dsh + DD[0];
+        better = llt(x, D[0]);
+      }
+      g.put_rec(par, M[Q - 1], I[Q - 1], D[Q - 1], m);
+      g.sync();
+      lf Mp, Ip, Dp;
+      float Es;
+      bool could;
+      g.get_prev(par, Mp, Ip, Dp);
+      g.get_e_could_row(par, s, Erun, Es, could);
+      lf const Msh0 = g.seg_shift_up(M[Q - 1], Mp);
+      lf const Ish0 = g.seg_shift_up(I[Q - 1], Ip);
+      lf Dsh0;
+      if (!could)
+      {
+        D[0] = lsel(g.seg_first(), lmin(Mp + MD[0], Dp + DD[0]), D[0]);
+#pragma unroll
+        for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+        Dsh0 = g.seg_shift_up(D[Q - 1], Dp);
+        x = Dsh0 + DD[0];
+        better = llt(x, D[0]);
+        while (g.seg_any(better))
+        {
+          D[0] = lmin(D[0], x);
+#pragma unroll
+          for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+          Dsh0 = g.seg_shift_up(D[Q - 1], Dp);
+          x = Dsh0 + DD[0];
+          better = llt(x, D[0]);
+        }
+      }
+      else
+      {
+        g.note_fallback();
+        D[0] = Msh0 + MD[0];
+#pragma unroll
+        for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
+        g.put_last(GS_D, D[Q - 1]);
+        g.sync();
+        Dsh0 = g.get_shift_carry(GS_D, D[Q - 1], Dp);
+        x = Dsh0 + DD[0];
+        better = llt(x, D[0]);
+        g.put_any(GS_F, better);
+        g.sync();
+        while (g.get_any(GS_F, better))
+        {
+          D[0] = lmin(D[0], x);
+#pragma unroll
+          for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+          g.put_last(GS_D, D[Q - 1]);
+          g.sync();
+          Dsh0 = g.get_shift_carry(GS_D, D[Q - 1], Dp);
+          x = Dsh0 + DD[0];
+          better = llt(x, D[0]);
+          g.put_any(GS_F, better);
+          g.sync();
+        }
+      }
+      Erun = __builtin_fminf(Erun, Es);
+
+      // fold this strip of row l into ring slot P (it held row l-5, already consumed above)
+      lf rest[Q], ipre[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+      {
+        lf const Ml = q ? M[q ? q - 1 : 0] : Msh0;
+        lf const Il = q ? I[q ? q - 1 : 0] : Ish0;
+        lf const Dl = q ? D[q ? q - 1 : 0] : Dsh0;
+        rest[q] = lmin3(Ml + MM[q], Il + IM[q], Dl + DM[q]);
+        ipre[q] = lmin(I[q] + II[q], M[q] + MI[q]);
+      }
+      store_q<Q>(ring + (size_t)P * Kp + col, lane, rest);
+      store_q<Q>(ring + (size_t)(5 + P) * Kp + col, lane, ipre);
+      if (STORE)
+      {
+        float *trow = tab_cells + (size_t)l * 3 * (size_t)Kp + col;
+        store_q<Q>(trow, lane, M);
+        store_q<Q>(trow + Kp, lane, I);
+        store_q<Q>(trow + 2 * (size_t)Kp, lane, D);
+      }
+      // what stands in front of wave 0 in the next exchange: this strip's last position, or
+      // nothing when the next exchange opens a new row
+      if (s + 1 < S)
+        g.put_carry(tick, M[Q - 1], I[Q - 1], D[Q - 1]);
+      else
+        g.put_carry_inf(tick);
+    }
+    E = Erun;
+    float N, J;
+    g.get_nj(GS_X0 + (l & 1), X, N, J);
+    float const B = __builtin_fminf(__builtin_fminf(N + NB, E + EB), J + JB); // c-core/viterbi.c:495-496,582-583
+    Bz[P] = B;
+    Spre[P] = lmin(lf_splat(E) + sa, X + sb);
+    if (STORE)
+    {
+      float const C = g.get_lane(GS_X0 + (l & 1), X, 2);
+      store_sp_lane0(tab_sp + (size_t)l * DCP_SP_STRIDE, lane, lf_splat(N), lf_splat(B), lf_splat(J), lf_splat(E),
+                     lf_splat(C));
+    }
+  }
+
+  // out[0] = viterbi_null(), out[1] = viterbi_cost()
+  DCP_FN void run(int L, float *out)
+  {
+    int l = 1;
+    for (; l + 4 <= L; l += 5)
+    {
+      row<1>(l);
+      row<2>(l + 1);
+      row<3>(l + 2);
+      row<4>(l + 3);
+      row<0>(l + 4);
+    }
+    if (l <= L) row<1>(l++);
+    if (l <= L) row<2>(l++);
+    if (l <= L) row<3>(l++);
+    if (l <= L) row<4>(l++);
+    g.sync();
+    g.put_lanes4(GS_X, X);
+    g.sync();
+    float const C = g.get_lane(GS_X, X, 2);
+    float const R = g.get_lane(GS_X, X, 3);
+    float const T = L > 0 ? __builtin_fminf(E + ET, C + CT) : DCP_INF;
+    store_f32_lane0(out + 0, g.lane, R);
+    store_f32_lane0(out + 1, g.lane, T);
+  }
+};
+
+// =============================================================================
 // Back-pointers.  Pointers depend on the ORDER of the reference's strict-<
 // updates whenever two candidates tie exactly in fp32, so this pass keeps the
 // reference's structure: for t = min(5,l)..1, each candidate as (x + trans) + emis,

@@ -5,8 +5,13 @@
 
 // kernel classes (Q positions per lane, W wavefronts per problem):
 //   0..3: (1..4, 1) K <= 64..256;  4..7: (4, 2/4/8/16) K <= 512/1024/2048/4096
-#define DCP_NUM_CLASSES 8
-#define DCP_MAX_CORE_SIZE 4096
+#define DCP_NUM_CLASSES 9
+#define DCP_STRIP_CLASS 8       // K > 4096: strips of DCP_STRIP_POSITIONS, state ring in HBM (StripWave)
+#define DCP_STRIP_POSITIONS 2048 // 64 lanes x 4 positions x 8 wavefronts
+#define DCP_MAX_CORE_SIZE 16383 // state ids keep 14 bits for k + 1 (c-core/state.h:27-39)
+// per-problem ring scratch of the strip class: rest[5][Kp] + Ipre[5][Kp] floats at the largest Kp
+#define DCP_RING_FLOATS ((size_t)10 * DCP_MAX_STRIPS * DCP_STRIP_POSITIONS)
+#define DCP_RING_SLOTS 1024 // workgroups of the strip kernel in flight (each takes problems in turn)
 int dcp_class_of(int K);                      // -1 when K is not covered
 void dcp_class_shape(int cls, int *Q, int *W);
 
@@ -19,6 +24,7 @@ struct DcpLaunch
   float const *xt_table;         // device, [rows][DCP_XT_STRIDE]
   float *out;                    // device: cost pass [2*slots] (null, alt); path pass [slots]
   unsigned char *arena;          // device: trellises (path pass only)
+  float *ring = nullptr;         // device: strip class only, DCP_RING_SLOTS x DCP_RING_FLOATS
   int nprob;
   hipStream_t stream;
 };

@@ -8,6 +8,8 @@
 #include "traceback.h"
 #include "viterbi_kernels.h"
 
+// (tried: holding Q = 3 / 4 to 96 / 128 VGPRs for 5 / 4 waves per SIMD -- the 6-7 scratch reloads per row cost
+// far more than the occupancy gives: 881 -> 620 GCUPS at K = 173, 1000 -> 878 at K = 256)
 template <int Q, int W>
 __global__ __launch_bounds__(64 * W) void dcp_cost_kernel(float const *__restrict__ pool,
                                                       DcpProfileDev const *__restrict__ profiles,
@@ -46,6 +48,34 @@ __global__ __launch_bounds__(64 * W) void dcp_cost_store_kernel(float const *__r
   w.tab_cells = w.tab_sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
   w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
   w.run(pb.L, out + 2 * (size_t)pb.out);
+}
+
+// Profiles beyond 4096 positions: one workgroup walks each row strip by strip (StripWave).
+template <int Q, int W, bool STORE>
+__global__ __launch_bounds__(64 * W) void dcp_strip_kernel(float const *__restrict__ pool,
+                                                       DcpProfileDev const *__restrict__ profiles,
+                                                       DcpProblem const *__restrict__ problems,
+                                                       DcpCodeRow const *__restrict__ code_rows,
+                                                       float const *__restrict__ xt_table,
+                                                       unsigned char *__restrict__ arena, float *__restrict__ ring,
+                                                       float *__restrict__ out, int nprob)
+{
+  // the grid is at most DCP_RING_SLOTS workgroups, each owning one ring and taking problems in turn
+  for (int p = (int)blockIdx.x; p < nprob; p += (int)gridDim.x)
+  {
+    DcpProblem const pb = problems[p];
+    DcpProfileDev const pf = profiles[pb.profile];
+    StripWave<Q, W, STORE> w;
+    w.ring = ring + (size_t)blockIdx.x * DCP_RING_FLOATS;
+    if (STORE)
+    {
+      w.tab_sp = reinterpret_cast<float *>((uintptr_t)arena + (uintptr_t)pb.trellis);
+      w.tab_cells = w.tab_sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
+    }
+    w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
+    w.run(pb.L, out + 2 * (size_t)pb.out);
+    __syncthreads(); // the next problem re-initialises the LDS records
+  }
 }
 
 // Fast path pass, step 2: one WAVEFRONT walks one window's DP table back from T to S.
@@ -449,6 +479,15 @@ template <int Q, int W> static hipError_t launch_path_qw(DcpLaunch const &a)
   return hipGetLastError();
 }
 
+template <bool STORE> static hipError_t launch_strip(DcpLaunch const &a)
+{
+  if (!a.ring) return hipErrorInvalidValue;
+  unsigned const grid = (unsigned)(a.nprob < DCP_RING_SLOTS ? a.nprob : DCP_RING_SLOTS);
+  hipLaunchKernelGGL((dcp_strip_kernel<4, 8, STORE>), dim3(grid), dim3(512), 0, a.stream, a.pool,
+                     a.profiles, a.problems, a.code_rows, a.xt_table, a.arena, a.ring, a.out, a.nprob);
+  return hipGetLastError();
+}
+
 int dcp_class_of(int K)
 {
   if (K < 1) return -1;
@@ -457,13 +496,14 @@ int dcp_class_of(int K)
   if (K <= 1024) return 5;
   if (K <= 2048) return 6;
   if (K <= 4096) return 7;
+  if (K <= DCP_MAX_CORE_SIZE) return DCP_STRIP_CLASS;
   return -1;
 }
 
 void dcp_class_shape(int cls, int *Q, int *W)
 {
-  static int const q[DCP_NUM_CLASSES] = {1, 2, 3, 4, 4, 4, 4, 4};
-  static int const w[DCP_NUM_CLASSES] = {1, 1, 1, 1, 2, 4, 8, 16};
+  static int const q[DCP_NUM_CLASSES] = {1, 2, 3, 4, 4, 4, 4, 4, 4};
+  static int const w[DCP_NUM_CLASSES] = {1, 1, 1, 1, 2, 4, 8, 16, 8}; // the strip class: per strip
   *Q = q[cls];
   *W = w[cls];
 }
@@ -481,6 +521,7 @@ hipError_t dcp_launch_cost(int cls, DcpLaunch const &a)
   case 5: return launch_cost_qw<4, 4>(a);
   case 6: return launch_cost_qw<4, 8>(a);
   case 7: return launch_cost_qw<4, 16>(a);
+  case DCP_STRIP_CLASS: return launch_strip<false>(a);
   default: return hipErrorInvalidValue;
   }
 }
@@ -505,6 +546,7 @@ hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a)
   case 5: return launch_store_qw<4, 4>(a);
   case 6: return launch_store_qw<4, 8>(a);
   case 7: return launch_store_qw<4, 16>(a);
+  case DCP_STRIP_CLASS: return launch_strip<true>(a);
   default: return hipErrorInvalidValue;
   }
 }

@@ -115,7 +115,7 @@ class Oracle:
         return np.float32(score), xnodes, nodes
 
     def unzip(self, K: int, L: int, xnodes: np.ndarray, nodes: np.ndarray):
-        cap = 2 * L + 16
+        cap = 2 * L + 2 * K + 64  # delete runs: up to K mute steps
         ids = np.empty(cap, dtype=np.int32)
         sizes = np.empty(cap, dtype=np.int32)
         n = self.lib.orc_unzip(K, L, xnodes, nodes, ids, sizes, cap)

@@ -65,12 +65,13 @@ def choose_qw(K: int):
     raise ValueError("core size beyond 4096")
 
 
-def pack_profile(prof: Profile, Q: int | None = None, W: int | None = None):
-    """-> (pool float32[...], ProfileDev) in the padded layout the kernels read."""
+def pack_profile(prof: Profile, Q: int | None = None, W: int | None = None, strips: int = 1):
+    """-> (pool float32[...], ProfileDev) in the padded layout the kernels read
+    (strips > 1: the StripWave layout, Kp = strips * 64 * Q * W)."""
     K = prof.K
     if Q is None or W is None:
         Q, W = choose_qw(K)
-    Kp = 64 * Q * W
+    Kp = 64 * Q * W * strips
     assert K <= Kp
     rows = np.full((TABLE_SIZE, ROW_HDR + Kp), INF, dtype=np.float32)
     rows[:, 0] = prof.null

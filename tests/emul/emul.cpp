@@ -108,3 +108,44 @@ extern "C" long emul_fallback_rows(void)
   em_fallback_rows = 0;
   return n;
 }
+
+// ---- StripWave: profiles longer than one workgroup's registers, strip by strip ----
+template <int Q, int W>
+static void strip_q(float const *pool, DcpProfileDev const &pf, DcpCodeRow const *codes, int L, float const *xt,
+                    float *out, float *ring, float *cells, float *sp)
+{
+  if (cells)
+  {
+    static thread_local StripWave<Q, W, true> w;
+    w.tab_cells = cells;
+    w.tab_sp = sp;
+    w.ring = ring;
+    w.tick = 0;
+    w.init(pool, pf, codes, xt);
+    w.run(L, out);
+  }
+  else
+  {
+    static thread_local StripWave<Q, W, false> w;
+    w.ring = ring;
+    w.tick = 0;
+    w.init(pool, pf, codes, xt);
+    w.run(L, out);
+  }
+}
+
+// ring: float[10 * Kp] scratch; cells/sp: the DP table or NULL
+extern "C" int emul_strip_cost(float const *pool, DcpProfileDev const *pf, DcpCodeRow const *codes, int L,
+                               float const *xt, float *out, float *ring, float *cells, float *sp)
+{
+  switch (pf->Q * 100 + pf->W)
+  {
+  case 101: strip_q<1, 1>(pool, *pf, codes, L, xt, out, ring, cells, sp); return 0;
+  case 201: strip_q<2, 1>(pool, *pf, codes, L, xt, out, ring, cells, sp); return 0;
+  case 102: strip_q<1, 2>(pool, *pf, codes, L, xt, out, ring, cells, sp); return 0;
+  case 202: strip_q<2, 2>(pool, *pf, codes, L, xt, out, ring, cells, sp); return 0;
+  case 402: strip_q<4, 2>(pool, *pf, codes, L, xt, out, ring, cells, sp); return 0;
+  case 104: strip_q<1, 4>(pool, *pf, codes, L, xt, out, ring, cells, sp); return 0;
+  default: return -1;
+  }
+}

@@ -84,6 +84,8 @@ template <int W> struct Group
   {
     em_lanes = 64 * W;
     lane = lane_ids();
+    put_carry_inf(0);
+    put_carry_inf(1);
   }
   // ---- one-barrier rows: here the W waves are real 64-lane segments of the vector ----
   struct Rec { float m, i, d, e; };
@@ -122,10 +124,10 @@ template <int W> struct Group
     for (int i = 0; i < em_lanes; ++i)
     {
       int const w = i / 64;
-      Rec const &p = rec[par][w > 0 ? w - 1 : 0];
-      Mp.v[i] = w == 0 ? INFINITY : p.m;
-      Ip.v[i] = w == 0 ? INFINITY : p.i;
-      Dp.v[i] = w == 0 ? INFINITY : p.d;
+      Rec const &p = w > 0 ? rec[par][w - 1] : carry[par];
+      Mp.v[i] = p.m;
+      Ip.v[i] = p.i;
+      Dp.v[i] = p.d;
     }
   }
   void get_e_could(int par, float &E, bool &could)
@@ -147,6 +149,37 @@ template <int W> struct Group
     N = X.v[0];
     J = X.v[1];
   }
+  // ---- StripWave ----
+  Rec carry[2];
+  float tdds[64][16];
+  template <int Q> void put_tdd_strip(int s, lf const (&DD)[Q])
+  {
+    for (int w = 0; w < W; ++w)
+    {
+      float t = 0.0f;
+      for (int i = 64 * w; i < 64 * w + 64; ++i)
+        for (int q = 0; q < Q; ++q)
+          if (!(i == 64 * w && q == 0)) t += DD[q].v[i];
+      tdds[s][w] = t;
+    }
+  }
+  void put_carry(int par, lf m, lf i, lf d) { carry[par] = Rec{m.v[em_lanes - 1], i.v[em_lanes - 1], d.v[em_lanes - 1], INFINITY}; }
+  void put_carry_inf(int par) { carry[par] = Rec{INFINITY, INFINITY, INFINITY, INFINITY}; }
+  void get_e_could_row(int par, int s, float floor_e, float &E, bool &could)
+  {
+    float m = rec[par][0].e;
+    for (int w = 1; w < W; ++w) m = fminf(m, rec[par][w].e);
+    float const lo = fminf(m, floor_e);
+    bool any = false;
+    for (int w = 0; w < W; ++w)
+    {
+      float const v = lo + tdds[s][w];
+      any = any || fminf(v * 0.9999f, v * 1.0001f) < rec[par][w].d;
+    }
+    E = m;
+    could = any;
+  }
+  lf get_shift_carry(int, lf x, lf fill) { return lane_shift_up(x, fill.v[0]); }
   void note_fallback() { ++em_fallback_rows; }
 
   void put_last(int, lf) {}

@@ -141,3 +141,63 @@ def test_minifam_consensus_pairs(em, orc):
     score, xn, nd = run_path(em, prof, xt, seq)
     s_o, xo, no = orc.path(prof, xt, seq)
     assert bits(score) == bits(s_o) and np.array_equal(xn, xo) and np.array_equal(nd, no)
+
+
+def test_strip_mined_profiles(em, orc):
+    """StripWave: a profile wider than one workgroup is walked strip by strip with the ring of
+    folded rows in memory, B applied when a row is used, and the previous strip standing in
+    front of wave 0.  Small strips here (64..512 positions) so that every boundary case is
+    hit in a few rows; scores and the traceback over the stored table against the oracle."""
+    rng = np.random.default_rng(23)
+    em.emul_fallback_rows.restype = C.c_long
+    em.emul_traceback.restype = C.c_int
+    shapes = [(1, 1, 3), (2, 1, 2), (1, 2, 3), (2, 2, 2), (4, 2, 2), (1, 4, 2), (1, 1, 5), (2, 2, 3)]
+    nfallback = 0
+    for it in range(64):
+        Q, W, S = shapes[it % len(shapes)]
+        KS = 64 * Q * W
+        K = int(rng.integers(KS * (S - 1) + 1, KS * S + 1))
+        if it % 7 == 0:
+            K = KS * S  # no padding at all
+        if it % 11 == 0:
+            K = KS * (S - 1) + 1  # one position in the last strip
+        quant = [None, 1.0, None, 4.0][it % 4]
+        prof = synth_profile(rng, K, quant, [0, 0.05][it % 2])
+        if it % 3 == 0:  # delete runs that cross waves and strips
+            prof.trans[7, 1:] = np.float32(0.01)
+            prof.trans[3, 1:] = np.float32(0.02)
+            prof.trans[1, 1:] = np.float32(9.0)
+            prof.match[:, K // 3:] += np.float32(30.0)
+        seq = random_seq(rng, int(rng.integers(1, 24)))
+        L = len(seq)
+        xt = orc.xtrans(max(L // 3, 1), it % 2, (it // 2) % 2)
+        if quant:
+            xt = (np.round(xt / quant) * quant).astype(np.float32)
+        pool, pd = pack_profile(prof, Q, W, S)
+        rows = code_rows(seq)
+        xt16 = np.zeros(16, np.float32)
+        xt16[:13] = xt
+        ring = np.full(10 * pd.Kp, np.nan, np.float32)
+        out = np.zeros(2, np.float32)
+        em.emul_fallback_rows()
+        assert em.emul_strip_cost(_vp(pool), C.byref(pd), _vp(rows), L, _vp(xt16), _vp(out), _vp(ring), None, None) == 0
+        nfallback += em.emul_fallback_rows()
+        assert bits(out[0]) == bits(orc.null(prof, xt, seq)), (it, K, Q, W, S)
+        assert bits(out[1]) == bits(orc.cost(prof, xt, seq)), (it, K, Q, W, S)
+        # the same with the DP table kept, then the traceback of the fast path pass
+        cells = np.full((L + 1) * 3 * pd.Kp, np.nan, np.float32)
+        sp = np.full((L + 1) * 8, np.nan, np.float32)
+        out2 = np.zeros(2, np.float32)
+        assert em.emul_strip_cost(_vp(pool), C.byref(pd), _vp(rows), L, _vp(xt16), _vp(out2), _vp(ring), _vp(cells), _vp(sp)) == 0
+        assert bits(out2[1]) == bits(out[1])
+        cap = 2 * L + 2 * K + 64
+        buf = np.zeros(cap, np.uint32)
+        n = em.emul_traceback(_vp(pool), C.byref(pd), _vp(rows), L, _vp(xt16), _vp(cells), _vp(sp), _vp(buf), C.c_long(cap))
+        if n > 0:  # n < 0: an exact tie the values cannot resolve (the literal pass takes over)
+            _, xo, no = orc.path(prof, xt, seq)
+            ids, sizes = orc.unzip(K, L, xo, no)
+            w = buf[cap - n:]
+            assert np.array_equal(w & 0xFFFF, ids.astype(np.uint32)) and np.array_equal(w >> 16, sizes.astype(np.uint32)), (it, K)
+        else:
+            assert n == -2, (it, K, n)
+    assert nfallback > 0

@@ -210,8 +210,55 @@ def test_long_profiles_multi_wave_kernels(engine, orc):
         assert np.array_equal(paths[i]["xnodes"], xo), (wins[i], profs[pi].K)
         assert np.array_equal(paths[i]["nodes"], no), (wins[i], profs[pi].K)
     with pytest.raises(Exception):
-        big = synth_profile(rng, 4097)
+        big = synth_profile(rng, 16384)  # state ids keep 14 bits for k + 1
         engine.add_profile(big.K, big.trans, big.match, big.null, big.bg)
+
+
+def test_profiles_beyond_4096_strip_by_strip(engine, orc):
+    """K = 4097..16383: one workgroup walks every row in strips of 2048 positions with the
+    folded rows in HBM (StripWave).  Scores and the fast path pass against the oracle; the
+    pass-by-pass kernel does not cover this range, so a packed trellis is refused."""
+    import deciphon_amd
+
+    rng = np.random.default_rng(53)
+    Ks = (4097, 6000, 8192, 12289, 16383)
+    profs = []
+    for i, K in enumerate(Ks):
+        p = synth_profile(rng, K, None, [0, 0.02][i % 2])
+        if i % 2 == 0:  # delete runs that cross strips
+            p.trans[7, 1:] = np.float32(0.01)
+            p.trans[3, 1:] = np.float32(0.02)
+            p.match[:, K // 2:] += np.float32(20.0)
+        profs.append(p)
+    small = synth_profile(rng, 200, None, 0.0)
+    seqs = [random_seq(rng, int(n)) for n in (1, 7, 23, 40)]
+    engine.clear_profiles()
+    for p in profs + [small]:
+        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    engine.commit()
+    engine.set_sequences(seqs)
+    engine.set_mode(True, False)
+    wins = [(pi, si, 0, len(seqs[si])) for pi in range(len(profs) + 1) for si in range(len(seqs))]
+    wins.append((1, 3, 5, 30))
+    nul, alt = engine.cost(wins)
+    allp = profs + [small]
+    for i, (pi, si, a, b) in enumerate(wins):
+        seq = np.ascontiguousarray(seqs[si][a:b])
+        xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+        assert bits(nul[i]) == bits(orc.null(allp[pi], xt, seq)), wins[i]
+        assert bits(alt[i]) == bits(orc.cost(allp[pi], xt, seq)), (wins[i], allp[pi].K)
+    paths = engine.path(wins, trellis=False)
+    assert engine.path_redone == 0
+    for i, (pi, si, a, b) in enumerate(wins):
+        seq = np.ascontiguousarray(seqs[si][a:b])
+        xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+        score, xo, no = orc.path(allp[pi], xt, seq)
+        ids, sizes = orc.unzip(allp[pi].K, len(seq), xo, no)
+        assert bits(paths[i]["score"]) == bits(score)
+        assert np.array_equal(paths[i]["state_ids"], ids) and np.array_equal(paths[i]["seqsizes"], sizes), wins[i]
+    with pytest.raises(deciphon_amd.HipError) as e:
+        engine.path(wins[:1], trellis=True)
+    assert e.value.code == 63  # DCP_ELARGECORESIZE
 
 
 def test_empty_and_invalid_calls(engine):
