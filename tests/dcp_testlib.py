@@ -62,7 +62,7 @@ def choose_qw(K: int):
     for W in (2, 4, 8, 16):
         if K <= 256 * W:
             return 4, W
-    raise ValueError("core size beyond 4096")
+    raise ValueError("core size beyond 4096: the strip class (pack_profile(..., strips=))")
 
 
 def pack_profile(prof: Profile, Q: int | None = None, W: int | None = None, strips: int = 1):
