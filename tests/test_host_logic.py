@@ -8,7 +8,7 @@ import pytest
 
 import deciphon_amd
 from deciphon_amd import host
-from dcp_testlib import GOLDEN, random_seq, read_fasta, synth_profile
+from dcp_testlib import GOLDEN, ROOT, random_seq, read_fasta, synth_profile
 from oracle.dcp_reader import read_dcp
 
 
@@ -180,3 +180,22 @@ def test_no_cpu_fallback():
     with pytest.raises(deciphon_amd.HipError) as e:
         deciphon_amd.Engine(0)
     assert e.value.code == 8  # DCP_EFUNCUSE
+
+
+def test_host_reader_under_sanitizers(tmp_path):
+    """The C++ host side that never touches the GPU (.dcp reader, windows, partitions) built
+    with -fsanitize=address,undefined and run over the golden database, truncated copies and
+    200 randomly corrupted copies: every one must parse or fail with an error code."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "deciphon_amd", "csrc")
+    exe = str(tmp_path / "host_sanitize")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-fno-omit-frame-pointer", "-I", csrc, "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "host_sanitize.cpp"), os.path.join(csrc, "host_logic.cpp"),
+                    os.path.join(csrc, "dcp_db.cpp"), os.path.join(csrc, "host_capi.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe, os.path.join(GOLDEN, "minifam.dcp"), str(tmp_path / "cut.dcp")], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "fuzz done" in r.stdout and "K=173 acc=PF00742.20 rc=0" in r.stdout
+    assert "window 1 [7959,10000)" in r.stdout  # c-core/window.c on a 10 kb read, K = 173 (SURVEY 8a-W)
