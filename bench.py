@@ -224,7 +224,7 @@ def main():
                                  "the HBM share (traffic = measured HBM bytes per step); the binding limit is "
                                  "instruction issue, see DESIGN.md section 5"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed once (N = 1) on the host cores
             cores = min(os.cpu_count() or 1, 16)
             out["cpu_baseline"] = cpu_baseline(db, reads, cores)
         print(json.dumps(out))
