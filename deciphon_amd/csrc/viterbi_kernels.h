@@ -5,8 +5,8 @@
 
 // kernel classes (Q positions per lane, W wavefronts per problem):
 //   0..3: (1..4, 1) K <= 64..256;  4..7: (4, 2/4/8/16) K <= 512/1024/2048/4096
-#define DCP_NUM_CLASSES 9
-#define DCP_STRIP_CLASS 8       // K > 4096: strips of DCP_STRIP_POSITIONS, state ring in HBM (StripWave)
+#define DCP_NUM_CLASSES 12
+#define DCP_STRIP_CLASS 11      // K > 4096: strips of DCP_STRIP_POSITIONS, state ring in HBM (StripWave)
 #define DCP_STRIP_POSITIONS 2048 // 64 lanes x 4 positions x 8 wavefronts
 #define DCP_MAX_CORE_SIZE 16383 // state ids keep 14 bits for k + 1 (c-core/state.h:27-39)
 // per-problem ring scratch of the strip class: rest[5][Kp] + Ipre[5][Kp] floats at the largest Kp

@@ -492,18 +492,22 @@ int dcp_class_of(int K)
 {
   if (K < 1) return -1;
   if (K <= 256) return (K + 63) / 64 - 1; // classes 0..3: one wave, Q = 1..4
-  if (K <= 512) return 4;
-  if (K <= 1024) return 5;
-  if (K <= 2048) return 6;
-  if (K <= 4096) return 7;
+  // several wavefronts per problem; the Q = 3 shapes keep lane padding under a quarter
+  if (K <= 384) return 4;
+  if (K <= 512) return 5;
+  if (K <= 768) return 6;
+  if (K <= 1024) return 7;
+  if (K <= 1536) return 8;
+  if (K <= 2048) return 9;
+  if (K <= 4096) return 10;
   if (K <= DCP_MAX_CORE_SIZE) return DCP_STRIP_CLASS;
   return -1;
 }
 
 void dcp_class_shape(int cls, int *Q, int *W)
 {
-  static int const q[DCP_NUM_CLASSES] = {1, 2, 3, 4, 4, 4, 4, 4, 4};
-  static int const w[DCP_NUM_CLASSES] = {1, 1, 1, 1, 2, 4, 8, 16, 8}; // the strip class: per strip
+  static int const q[DCP_NUM_CLASSES] = {1, 2, 3, 4, 3, 4, 3, 4, 3, 4, 4, 4};
+  static int const w[DCP_NUM_CLASSES] = {1, 1, 1, 1, 2, 2, 4, 4, 8, 8, 16, 8}; // the strip class: per strip
   *Q = q[cls];
   *W = w[cls];
 }
@@ -517,10 +521,13 @@ hipError_t dcp_launch_cost(int cls, DcpLaunch const &a)
   case 1: return launch_cost_qw<2, 1>(a);
   case 2: return launch_cost_qw<3, 1>(a);
   case 3: return launch_cost_qw<4, 1>(a);
-  case 4: return launch_cost_qw<4, 2>(a);
-  case 5: return launch_cost_qw<4, 4>(a);
-  case 6: return launch_cost_qw<4, 8>(a);
-  case 7: return launch_cost_qw<4, 16>(a);
+  case 4: return launch_cost_qw<3, 2>(a);
+  case 5: return launch_cost_qw<4, 2>(a);
+  case 6: return launch_cost_qw<3, 4>(a);
+  case 7: return launch_cost_qw<4, 4>(a);
+  case 8: return launch_cost_qw<3, 8>(a);
+  case 9: return launch_cost_qw<4, 8>(a);
+  case 10: return launch_cost_qw<4, 16>(a);
   case DCP_STRIP_CLASS: return launch_strip<false>(a);
   default: return hipErrorInvalidValue;
   }
@@ -542,10 +549,13 @@ hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a)
   case 1: return launch_store_qw<2, 1>(a);
   case 2: return launch_store_qw<3, 1>(a);
   case 3: return launch_store_qw<4, 1>(a);
-  case 4: return launch_store_qw<4, 2>(a);
-  case 5: return launch_store_qw<4, 4>(a);
-  case 6: return launch_store_qw<4, 8>(a);
-  case 7: return launch_store_qw<4, 16>(a);
+  case 4: return launch_store_qw<3, 2>(a);
+  case 5: return launch_store_qw<4, 2>(a);
+  case 6: return launch_store_qw<3, 4>(a);
+  case 7: return launch_store_qw<4, 4>(a);
+  case 8: return launch_store_qw<3, 8>(a);
+  case 9: return launch_store_qw<4, 8>(a);
+  case 10: return launch_store_qw<4, 16>(a);
   case DCP_STRIP_CLASS: return launch_strip<true>(a);
   default: return hipErrorInvalidValue;
   }
@@ -576,10 +586,13 @@ hipError_t dcp_launch_path(int cls, DcpLaunch const &a)
   case 1: return launch_path_qw<2, 1>(a);
   case 2: return launch_path_qw<3, 1>(a);
   case 3: return launch_path_qw<4, 1>(a);
-  case 4: return launch_path_qw<4, 2>(a);
-  case 5: return launch_path_qw<4, 4>(a);
-  case 6: return launch_path_qw<4, 8>(a);
-  case 7: return launch_path_qw<4, 16>(a);
+  case 4: return launch_path_qw<3, 2>(a);
+  case 5: return launch_path_qw<4, 2>(a);
+  case 6: return launch_path_qw<3, 4>(a);
+  case 7: return launch_path_qw<4, 4>(a);
+  case 8: return launch_path_qw<3, 8>(a);
+  case 9: return launch_path_qw<4, 8>(a);
+  case 10: return launch_path_qw<4, 16>(a);
   default: return hipErrorInvalidValue;
   }
 }

@@ -55,13 +55,13 @@ def synth_profile(rng, K: int, quant=None, pinf: float = 0.0) -> Profile:
 
 
 def choose_qw(K: int):
-    """(positions per lane, waves per problem): one wave up to K = 256, then 4 positions
-    per lane and 2/4/8/16 waves (deciphon_amd/csrc/engine.cpp: choose_class)."""
+    """(positions per lane, waves per problem): one wave up to K = 256, then 3 or 4 positions
+    per lane and 2/4/8/16 waves (deciphon_amd/csrc/viterbi_kernels.hip: dcp_class_of)."""
     if K <= 256:
         return max(1, (K + 63) // 64), 1
-    for W in (2, 4, 8, 16):
-        if K <= 256 * W:
-            return 4, W
+    for Q, W in ((3, 2), (4, 2), (3, 4), (4, 4), (3, 8), (4, 8), (4, 16)):
+        if K <= 64 * Q * W:
+            return Q, W
     raise ValueError("core size beyond 4096: the strip class (pack_profile(..., strips=))")
 
 

@@ -32,6 +32,9 @@ extern "C" int emul_cost(float const *pool, DcpProfileDev const *pf, DcpCodeRow 
   case 201: cost_q<2, 1>(pool, *pf, c, L, xt, out); return 0;
   case 301: cost_q<3, 1>(pool, *pf, c, L, xt, out); return 0;
   case 401: cost_q<4, 1>(pool, *pf, c, L, xt, out); return 0;
+  case 302: cost_q<3, 2>(pool, *pf, c, L, xt, out); return 0;
+  case 304: cost_q<3, 4>(pool, *pf, c, L, xt, out); return 0;
+  case 308: cost_q<3, 8>(pool, *pf, c, L, xt, out); return 0;
   case 402: cost_q<4, 2>(pool, *pf, c, L, xt, out); return 0;
   case 404: cost_q<4, 4>(pool, *pf, c, L, xt, out); return 0;
   case 408: cost_q<4, 8>(pool, *pf, c, L, xt, out); return 0;
@@ -50,6 +53,9 @@ extern "C" int emul_path(float const *pool, DcpProfileDev const *pf, DcpCodeRow 
   case 201: *score = path_q<2, 1>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
   case 301: *score = path_q<3, 1>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
   case 401: *score = path_q<4, 1>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 302: *score = path_q<3, 2>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 304: *score = path_q<3, 4>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
+  case 308: *score = path_q<3, 8>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
   case 402: *score = path_q<4, 2>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
   case 404: *score = path_q<4, 4>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
   case 408: *score = path_q<4, 8>(pool, *pf, c, L, xt, xnodes, nodes); return 0;
@@ -79,6 +85,8 @@ extern "C" int emul_cost_store(float const *pool, DcpProfileDev const *pf, DcpCo
   case 201: store_q_<2, 1>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
   case 301: store_q_<3, 1>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
   case 401: store_q_<4, 1>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
+  case 302: store_q_<3, 2>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
+  case 304: store_q_<3, 4>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
   case 402: store_q_<4, 2>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
   case 404: store_q_<4, 4>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
   default: return -1;
