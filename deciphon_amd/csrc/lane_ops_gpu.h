@@ -386,6 +386,19 @@ template <> DCP_FN void load_q<4>(float const *__restrict__ row, lu lane, lf (&o
   out[3] = v.w;
 }
 
+template <> DCP_FN void load_q<6>(float const *__restrict__ row, lu lane, lf (&out)[6])
+{
+  float2 const *p = reinterpret_cast<float2 const *>(row + (size_t)lane * 6); // 24-byte elements, 8-byte aligned
+  float2 const a = p[0], b = p[1], c = p[2];
+  out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y; out[4] = c.x; out[5] = c.y;
+}
+template <> DCP_FN void load_q<8>(float const *__restrict__ row, lu lane, lf (&out)[8])
+{
+  float4 const *p = reinterpret_cast<float4 const *>(row + (size_t)lane * 8);
+  float4 const a = p[0], b = p[1];
+  out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+}
+
 // ---- emission rows: { null, bg, 0, 0, match[0..Kp) } behind one scalar byte offset ----
 // Addressed through a buffer resource: the row offset travels in an SGPR (soffset) and
 // the lane's own offset in one VGPR computed once, so a row read costs no VALU at all.
@@ -444,6 +457,22 @@ template <> DCP_FN void load_row_q<4>(RowSrc const &r, lu voff, uint32_t soff, l
   out[3] = __uint_as_float(v.w);
 }
 
+template <> DCP_FN void load_row_q<6>(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[6])
+{
+  dcp_u32x4 const a = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, voff, soff, 0);
+  dcp_u32x2 const b = __builtin_amdgcn_raw_buffer_load_b64(r.rsrc, voff + 16u, soff, 0);
+  out[0] = __uint_as_float(a.x); out[1] = __uint_as_float(a.y); out[2] = __uint_as_float(a.z);
+  out[3] = __uint_as_float(a.w); out[4] = __uint_as_float(b.x); out[5] = __uint_as_float(b.y);
+}
+template <> DCP_FN void load_row_q<8>(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[8])
+{
+  dcp_u32x4 const a = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, voff, soff, 0);
+  dcp_u32x4 const b = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, voff + 16u, soff, 0);
+  out[0] = __uint_as_float(a.x); out[1] = __uint_as_float(a.y); out[2] = __uint_as_float(a.z);
+  out[3] = __uint_as_float(a.w); out[4] = __uint_as_float(b.x); out[5] = __uint_as_float(b.y);
+  out[6] = __uint_as_float(b.z); out[7] = __uint_as_float(b.w);
+}
+
 // one DP-table row plane: the lane's Q values at row[lane*Q ..], rows padded to Kp
 template <int Q> DCP_FN void store_q(float *__restrict__ row, lu lane, lf const (&v)[Q])
 {
@@ -457,6 +486,11 @@ template <int Q> DCP_FN void store_q(float *__restrict__ row, lu lane, lf const 
     p[2] = v[Q > 2 ? 2 : 0];
   }
   if (Q == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[Q > 1 ? 1 : 0], v[Q > 2 ? 2 : 0], v[Q > 3 ? 3 : 0]);
+  if (Q > 4)
+  {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) p[q] = v[q];
+  }
 }
 
 DCP_FN void store_sp_lane0(float *__restrict__ p, lu lane, lf N, lf B, lf J, lf E, lf C)

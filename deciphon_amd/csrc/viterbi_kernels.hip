@@ -492,7 +492,9 @@ int dcp_class_of(int K)
 {
   if (K < 1) return -1;
   if (K <= 256) return (K + 63) / 64 - 1; // classes 0..3: one wave, Q = 1..4
-  // several wavefronts per problem; the Q = 3 shapes keep lane padding under a quarter
+  // Kp = 384 W' / 512 W': the cost kernels take 6 positions per lane where Kp = 384 W' (half the
+  // wavefronts of the 3-per-lane shape: (6,1) runs at the per-cell rate of (4,1), 862 against 636 GCUPS
+  // for (3,2) at K = 384) -- 8 per lane needs 260 VGPRs, one wave per SIMD, and gains nothing over (4,2)
   if (K <= 384) return 4;
   if (K <= 512) return 5;
   if (K <= 768) return 6;
@@ -506,8 +508,10 @@ int dcp_class_of(int K)
 
 void dcp_class_shape(int cls, int *Q, int *W)
 {
-  static int const q[DCP_NUM_CLASSES] = {1, 2, 3, 4, 3, 4, 3, 4, 3, 4, 4, 4};
-  static int const w[DCP_NUM_CLASSES] = {1, 1, 1, 1, 2, 2, 4, 4, 8, 8, 16, 8}; // the strip class: per strip
+  // the shape of the cost / cost+store kernels; the pass-by-pass path kernel keeps at most 4 positions
+  // per lane and runs the same padded layout as (3, 2W) where this says (6, W)
+  static int const q[DCP_NUM_CLASSES] = {1, 2, 3, 4, 6, 4, 6, 4, 6, 4, 4, 4};
+  static int const w[DCP_NUM_CLASSES] = {1, 1, 1, 1, 1, 2, 2, 4, 4, 8, 16, 8}; // the strip class: per strip
   *Q = q[cls];
   *W = w[cls];
 }
@@ -521,11 +525,11 @@ hipError_t dcp_launch_cost(int cls, DcpLaunch const &a)
   case 1: return launch_cost_qw<2, 1>(a);
   case 2: return launch_cost_qw<3, 1>(a);
   case 3: return launch_cost_qw<4, 1>(a);
-  case 4: return launch_cost_qw<3, 2>(a);
+  case 4: return launch_cost_qw<6, 1>(a);
   case 5: return launch_cost_qw<4, 2>(a);
-  case 6: return launch_cost_qw<3, 4>(a);
+  case 6: return launch_cost_qw<6, 2>(a);
   case 7: return launch_cost_qw<4, 4>(a);
-  case 8: return launch_cost_qw<3, 8>(a);
+  case 8: return launch_cost_qw<6, 4>(a);
   case 9: return launch_cost_qw<4, 8>(a);
   case 10: return launch_cost_qw<4, 16>(a);
   case DCP_STRIP_CLASS: return launch_strip<false>(a);
@@ -549,11 +553,11 @@ hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a)
   case 1: return launch_store_qw<2, 1>(a);
   case 2: return launch_store_qw<3, 1>(a);
   case 3: return launch_store_qw<4, 1>(a);
-  case 4: return launch_store_qw<3, 2>(a);
+  case 4: return launch_store_qw<6, 1>(a);
   case 5: return launch_store_qw<4, 2>(a);
-  case 6: return launch_store_qw<3, 4>(a);
+  case 6: return launch_store_qw<6, 2>(a);
   case 7: return launch_store_qw<4, 4>(a);
-  case 8: return launch_store_qw<3, 8>(a);
+  case 8: return launch_store_qw<6, 4>(a);
   case 9: return launch_store_qw<4, 8>(a);
   case 10: return launch_store_qw<4, 16>(a);
   case DCP_STRIP_CLASS: return launch_strip<true>(a);

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from dcp_testlib import GOLDEN, ROOT, bits, code_rows, pack_profile, random_seq, read_fasta, synth_profile
+from dcp_testlib import GOLDEN, ROOT, bits, choose_qw, code_rows, pack_profile, random_seq, read_fasta, synth_profile
 from oracle.dcp_reader import read_dcp
 
 
@@ -34,7 +34,7 @@ def run_cost(em, prof, xt, seq):
 
 
 def run_path(em, prof, xt, seq):
-    pool, pd = pack_profile(prof)
+    pool, pd = pack_profile(prof, *choose_qw(prof.K, path=True))
     rows = code_rows(seq)
     xt16 = np.zeros(16, np.float32)
     xt16[:13] = xt
