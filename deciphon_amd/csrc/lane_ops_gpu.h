@@ -111,6 +111,35 @@ DCP_FN uint32_t read_laneu(lu x, int lane) { return (uint32_t)__builtin_amdgcn_r
 // per slot is enough.
 enum { GS_M, GS_I, GS_D, GS_E, GS_F, GS_X, GS_T0, GS_T1, GS_X0, GS_X1, GS_SLOTS };
 
+// Values parked in LDS between their uses (CostWave with 8 positions per lane): chunk j of a lane
+// sits at ((wave*4 + slot)*Q/4 + j)*64 + lane float4s, so a wave reads 64 consecutive float4s.
+#define DCP_STASH_SLOTS(W_) ((W_) > 1 ? 8 : 4)
+template <int Q, int W> DCP_FN float4 *dcp_stash_mem()
+{
+  static_assert(Q % 4 == 0, "whole float4 chunks");
+  __shared__ float4 mem[W * DCP_STASH_SLOTS(W) * (Q / 4) * 64];
+  return mem;
+}
+template <int Q, int W> DCP_FN void dcp_stash(int wave, lu lane, int slot, lf const (&v)[Q])
+{
+  float4 *mem = dcp_stash_mem<Q, W>() + (size_t)(wave * DCP_STASH_SLOTS(W) + slot) * (Q / 4) * 64 + (lane & 63u);
+#pragma unroll
+  for (int j = 0; j < Q / 4; ++j) mem[j * 64] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+template <int Q, int W> DCP_FN void dcp_unstash(int wave, lu lane, int slot, lf (&v)[Q])
+{
+  float4 const *mem = dcp_stash_mem<Q, W>() + (size_t)(wave * DCP_STASH_SLOTS(W) + slot) * (Q / 4) * 64 + (lane & 63u);
+#pragma unroll
+  for (int j = 0; j < Q / 4; ++j)
+  {
+    float4 const t = mem[j * 64];
+    v[4 * j] = t.x;
+    v[4 * j + 1] = t.y;
+    v[4 * j + 2] = t.z;
+    v[4 * j + 3] = t.w;
+  }
+}
+
 template <int W> struct Group;
 
 template <> struct Group<1>
@@ -123,6 +152,8 @@ template <> struct Group<1>
   DCP_FN void put_lanes4(int, lf) {}
   DCP_FN void put_any(int, lm) {}
   template <int Q> DCP_FN void put_tdd(lf const (&)[Q]) {}
+  template <int Q> DCP_FN void stash_q(int slot, lf const (&v)[Q]) { dcp_stash<Q, 1>(0, lane, slot, v); }
+  template <int Q> DCP_FN void unstash_q(int slot, lf (&v)[Q]) { dcp_unstash<Q, 1>(0, lane, slot, v); }
   DCP_FN void put_count(int, lm) {}
   DCP_FN void sync() {}
   DCP_FN lf get_shift(int, lf x, float fill) { return lane_shift_up(x, fill); }
@@ -193,6 +224,8 @@ template <int W> struct Group
     return __int_as_float(
         __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
   }
+  template <int Q> DCP_FN void stash_q(int slot, lf const (&v)[Q]) { dcp_stash<Q, W>(wave, lane, slot, v); }
+  template <int Q> DCP_FN void unstash_q(int slot, lf (&v)[Q]) { dcp_unstash<Q, W>(wave, lane, slot, v); }
   DCP_FN bool seg_any(lm m) const { return wave_any(m); }
   DCP_FN lm seg_first() const { return (lane & 63u) == 0u; }
   template <int Q> DCP_FN void put_tdd(lf const (&DD)[Q])

@@ -44,6 +44,10 @@
 // traceback.h -- the fast path pass.
 template <int Q, int W, bool STORE = false> struct CostWave
 {
+  // Q = 8: MD, DD, II, MI wait in LDS between their uses (a row needs them for a few instructions
+  // each), which brings the kernel from 260 to under 256 VGPRs -- two waves per SIMD instead of one
+  static constexpr bool STASH = Q >= 8;
+  static constexpr bool STASH6 = STASH && W > 1; // the multi-wave exchange needs more room: all eight
   Group<W> g;
   float *__restrict__ tab_cells = nullptr; // [(L+1)][3][Kp]
   float *__restrict__ tab_sp = nullptr;    // [(L+1)][DCP_SP_STRIDE]
@@ -105,6 +109,20 @@ template <int Q, int W, bool STORE = false> struct CostWave
     JBv = lf_pin(xt[DCP_JB]);
     shM = shI = shD = lf_splat(DCP_INF);
     g.put_tdd(DD); // W > 1: what running through a whole wave of delete states costs (row())
+    if constexpr (STASH)
+    {
+      g.template stash_q<Q>(0, MD);
+      g.template stash_q<Q>(1, DD);
+      g.template stash_q<Q>(2, II);
+      g.template stash_q<Q>(3, MI);
+      if constexpr (STASH6)
+      {
+        g.template stash_q<Q>(4, IM);
+        g.template stash_q<Q>(5, DM);
+        g.template stash_q<Q>(6, BM);
+        g.template stash_q<Q>(7, MM);
+      }
+    }
     ET = xt[DCP_ET];
     CT = xt[DCP_CT];
     RR = xt[DCP_RR];
@@ -162,6 +180,11 @@ template <int Q, int W, bool STORE = false> struct CostWave
     lf D[Q];
     lf Msh0, Ish0, Dsh0, B;
     float N, J;
+    if constexpr (STASH)
+    {
+      g.template unstash_q<Q>(0, MD);
+      g.template unstash_q<Q>(1, DD);
+    }
     if constexpr (W == 1)
     {
       Msh0 = lane_shift_up_keep(M[Q - 1], shM);
@@ -284,6 +307,18 @@ template <int Q, int W, bool STORE = false> struct CostWave
     }
 
     // fold row l into the ring (slot P held row l-5, no longer needed)
+    if constexpr (STASH)
+    {
+      g.template unstash_q<Q>(2, II);
+      g.template unstash_q<Q>(3, MI);
+      if constexpr (STASH6)
+      {
+        g.template unstash_q<Q>(4, IM);
+        g.template unstash_q<Q>(5, DM);
+        g.template unstash_q<Q>(6, BM);
+        g.template unstash_q<Q>(7, MM);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {

@@ -11,7 +11,7 @@
 // (tried: holding Q = 3 / 4 to 96 / 128 VGPRs for 5 / 4 waves per SIMD -- the 6-7 scratch reloads per row cost
 // far more than the occupancy gives: 881 -> 620 GCUPS at K = 173, 1000 -> 878 at K = 256)
 template <int Q, int W>
-__global__ __launch_bounds__(64 * W) void dcp_cost_kernel(float const *__restrict__ pool,
+__global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_kernel(float const *__restrict__ pool,
                                                       DcpProfileDev const *__restrict__ profiles,
                                                       DcpProblem const *__restrict__ problems,
                                                       DcpCodeRow const *__restrict__ code_rows,
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64 * W) void dcp_cost_kernel(float const *__restric
 // Fast path pass, step 1: the cost pass that also leaves the DP table of its window in the
 // arena: float specials[(L+1)][8] followed by float cells[(L+1)][3][Kp].
 template <int Q, int W>
-__global__ __launch_bounds__(64 * W) void dcp_cost_store_kernel(float const *__restrict__ pool,
+__global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_store_kernel(float const *__restrict__ pool,
                                                             DcpProfileDev const *__restrict__ profiles,
                                                             DcpProblem const *__restrict__ problems,
                                                             DcpCodeRow const *__restrict__ code_rows,
@@ -492,9 +492,12 @@ int dcp_class_of(int K)
 {
   if (K < 1) return -1;
   if (K <= 256) return (K + 63) / 64 - 1; // classes 0..3: one wave, Q = 1..4
-  // Kp = 384 W' / 512 W': the cost kernels take 6 positions per lane where Kp = 384 W' (half the
-  // wavefronts of the 3-per-lane shape: (6,1) runs at the per-cell rate of (4,1), 862 against 636 GCUPS
-  // for (3,2) at K = 384) -- 8 per lane needs 260 VGPRs, one wave per SIMD, and gains nothing over (4,2)
+  // Padded sizes 384, 512, 768, 1024, 1536, 2048, 4096.  The cost kernels run them with 6 or 8 positions per
+  // lane -- (6,1) (8,1) (6,2) (4,4) (6,4) (8,4) (8,8) -- which halves or quarters the wavefronts that meet at
+  // the row barrier; 8 per lane fits 256 VGPRs (two waves per SIMD) only with the transition arrays parked in
+  // LDS between their uses (CostWave::STASH).  Measured against the 3/4-per-lane shapes on Pfam-structured
+  // tables: K=384 639 -> 857 GCUPS, 512 674 -> 884, 768 517 -> 691, 1536 328 -> 593, 2048 427 -> 548,
+  // 4096 190 -> 337; (8,2) for 1024 brought nothing over (4,4).  The pass-by-pass path kernel keeps 3/4.
   if (K <= 384) return 4;
   if (K <= 512) return 5;
   if (K <= 768) return 6;
@@ -509,9 +512,9 @@ int dcp_class_of(int K)
 void dcp_class_shape(int cls, int *Q, int *W)
 {
   // the shape of the cost / cost+store kernels; the pass-by-pass path kernel keeps at most 4 positions
-  // per lane and runs the same padded layout as (3, 2W) where this says (6, W)
-  static int const q[DCP_NUM_CLASSES] = {1, 2, 3, 4, 6, 4, 6, 4, 6, 4, 4, 4};
-  static int const w[DCP_NUM_CLASSES] = {1, 1, 1, 1, 1, 2, 2, 4, 4, 8, 16, 8}; // the strip class: per strip
+  // per lane and runs the same padded layout as (3, 2W) / (4, 2W) where this says (6, W) / (8, W)
+  static int const q[DCP_NUM_CLASSES] = {1, 2, 3, 4, 6, 8, 6, 4, 6, 8, 8, 4};
+  static int const w[DCP_NUM_CLASSES] = {1, 1, 1, 1, 1, 1, 2, 4, 4, 4, 8, 8}; // the strip class: per strip
   *Q = q[cls];
   *W = w[cls];
 }
@@ -526,12 +529,12 @@ hipError_t dcp_launch_cost(int cls, DcpLaunch const &a)
   case 2: return launch_cost_qw<3, 1>(a);
   case 3: return launch_cost_qw<4, 1>(a);
   case 4: return launch_cost_qw<6, 1>(a);
-  case 5: return launch_cost_qw<4, 2>(a);
+  case 5: return launch_cost_qw<8, 1>(a);
   case 6: return launch_cost_qw<6, 2>(a);
   case 7: return launch_cost_qw<4, 4>(a);
   case 8: return launch_cost_qw<6, 4>(a);
-  case 9: return launch_cost_qw<4, 8>(a);
-  case 10: return launch_cost_qw<4, 16>(a);
+  case 9: return launch_cost_qw<8, 4>(a);
+  case 10: return launch_cost_qw<8, 8>(a);
   case DCP_STRIP_CLASS: return launch_strip<false>(a);
   default: return hipErrorInvalidValue;
   }
@@ -554,12 +557,12 @@ hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a)
   case 2: return launch_store_qw<3, 1>(a);
   case 3: return launch_store_qw<4, 1>(a);
   case 4: return launch_store_qw<6, 1>(a);
-  case 5: return launch_store_qw<4, 2>(a);
+  case 5: return launch_store_qw<8, 1>(a);
   case 6: return launch_store_qw<6, 2>(a);
   case 7: return launch_store_qw<4, 4>(a);
   case 8: return launch_store_qw<6, 4>(a);
-  case 9: return launch_store_qw<4, 8>(a);
-  case 10: return launch_store_qw<4, 16>(a);
+  case 9: return launch_store_qw<8, 4>(a);
+  case 10: return launch_store_qw<8, 8>(a);
   case DCP_STRIP_CLASS: return launch_strip<true>(a);
   default: return hipErrorInvalidValue;
   }

@@ -57,12 +57,12 @@ def synth_profile(rng, K: int, quant=None, pinf: float = 0.0) -> Profile:
 def choose_qw(K: int, path: bool = False):
     """(positions per lane, waves per problem) of the cost kernels -- or, path=True, of the
     pass-by-pass path kernel, which keeps at most 4 positions per lane and runs (3, 2W) where
-    the cost kernel runs (6, W) on the same padded layout
+    the cost kernel runs (6, W) / (8, W) on the same padded layout
     (deciphon_amd/csrc/viterbi_kernels.hip: dcp_class_of / dcp_class_shape / dcp_launch_path)."""
     if K <= 256:
         return max(1, (K + 63) // 64), 1
     shapes = ((3, 2), (4, 2), (3, 4), (4, 4), (3, 8), (4, 8), (4, 16)) if path else \
-             ((6, 1), (4, 2), (6, 2), (4, 4), (6, 4), (4, 8), (4, 16))
+             ((6, 1), (8, 1), (6, 2), (4, 4), (6, 4), (8, 4), (8, 8))
     for Q, W in shapes:
         if K <= 64 * Q * W:
             return Q, W

@@ -32,6 +32,10 @@ extern "C" int emul_cost(float const *pool, DcpProfileDev const *pf, DcpCodeRow 
   case 201: cost_q<2, 1>(pool, *pf, c, L, xt, out); return 0;
   case 301: cost_q<3, 1>(pool, *pf, c, L, xt, out); return 0;
   case 401: cost_q<4, 1>(pool, *pf, c, L, xt, out); return 0;
+  case 801: cost_q<8, 1>(pool, *pf, c, L, xt, out); return 0;
+  case 802: cost_q<8, 2>(pool, *pf, c, L, xt, out); return 0;
+  case 804: cost_q<8, 4>(pool, *pf, c, L, xt, out); return 0;
+  case 808: cost_q<8, 8>(pool, *pf, c, L, xt, out); return 0;
   case 601: cost_q<6, 1>(pool, *pf, c, L, xt, out); return 0;
   case 602: cost_q<6, 2>(pool, *pf, c, L, xt, out); return 0;
   case 604: cost_q<6, 4>(pool, *pf, c, L, xt, out); return 0;
@@ -88,6 +92,9 @@ extern "C" int emul_cost_store(float const *pool, DcpProfileDev const *pf, DcpCo
   case 201: store_q_<2, 1>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
   case 301: store_q_<3, 1>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
   case 401: store_q_<4, 1>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
+  case 801: store_q_<8, 1>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
+  case 802: store_q_<8, 2>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
+  case 804: store_q_<8, 4>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
   case 601: store_q_<6, 1>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
   case 602: store_q_<6, 2>(pool, *pf, codes, L, xt, out, cells, sp); return 0;
   case 302: store_q_<3, 2>(pool, *pf, codes, L, xt, out, cells, sp); return 0;

@@ -149,6 +149,10 @@ template <int W> struct Group
     N = X.v[0];
     J = X.v[1];
   }
+  // values parked between uses (LDS on the GPU)
+  lf stashv[8][8];
+  template <int Q> void stash_q(int slot, lf const (&v)[Q]) { for (int q = 0; q < Q; ++q) stashv[slot][q] = v[q]; }
+  template <int Q> void unstash_q(int slot, lf (&v)[Q]) { for (int q = 0; q < Q; ++q) v[q] = stashv[slot][q]; }
   // ---- StripWave ----
   Rec carry[2];
   float tdds[64][16];
