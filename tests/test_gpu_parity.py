@@ -209,6 +209,9 @@ def test_long_profiles_multi_wave_kernels(engine, orc):
         assert bits(paths[i]["score"]) == bits(score), (wins[i], profs[pi].K)
         assert np.array_equal(paths[i]["xnodes"], xo), (wins[i], profs[pi].K)
         assert np.array_equal(paths[i]["nodes"], no), (wins[i], profs[pi].K)
+        # the steps come from the fast pass (cost kernel of the class with the DP table kept + traceback)
+        ids, sizes = orc.unzip(profs[pi].K, len(seq), xo, no)
+        assert np.array_equal(paths[i]["state_ids"], ids) and np.array_equal(paths[i]["seqsizes"], sizes), wins[i]
     with pytest.raises(Exception):
         big = synth_profile(rng, 16384)  # state ids keep 14 bits for k + 1
         engine.add_profile(big.K, big.trans, big.match, big.null, big.bg)

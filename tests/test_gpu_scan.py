@@ -110,6 +110,33 @@ def test_sliding_windows_chain_like_test_window(tmp_path, orc):
     assert any(r.split("\t")[1] != "0" for r in rows)  # a hit in a later window
 
 
+def test_long_reads_with_error_bearing_domains_like_config5(tmp_path, orc):
+    """SURVEY 8(d) config 5 in small: 50 kb reads with planted domains carrying 12 % errors
+    (8 % substitutions, 2 % insertions, 2 % deletions), about 7 chained windows per
+    (profile, read) pair; every product row (window chain, hit span, lrt, every step of every
+    path) against the oracle-driven restatement of thread_run."""
+    rng = np.random.default_rng(59)
+    cons = [t for _, t in read_fasta(os.path.join(GOLDEN, "consensus.fna"))]
+    reads = []
+    for sid in range(3):
+        text = ["ACGT"[i] for i in rng.integers(0, 4, size=50000)]
+        for at in sorted(rng.integers(0, 48000, size=7)):
+            dom = []
+            for ch in cons[int(rng.integers(0, len(cons)))]:
+                u = rng.random()
+                if u < 0.02:
+                    continue
+                if u < 0.04:
+                    dom.append("ACGT"[rng.integers(0, 4)])
+                dom.append("ACGT"[rng.integers(0, 4)] if rng.random() < 0.08 else ch)
+            text[at : at + len(dom)] = dom
+        reads.append((100 + sid, "".join(text[:50000])))
+    rows = run_scan(str(tmp_path), reads)
+    want = oracle_scan(orc, read_dcp(DCP), reads, True, False)
+    assert rows == want
+    assert len(rows) >= 10 and len({r.split("\t")[1] for r in rows}) >= 4  # hits in several windows of the chains
+
+
 def test_partitions_concatenate_to_the_whole_scan(tmp_path, orc):
     """Contiguous profile partitions (c-core/partition_size.c) scanned separately give, in
     partition order, exactly the rows of the unpartitioned scan (c-core/product.c:63-81)."""
