@@ -26,6 +26,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <deque>
+#include <memory>
 #include <string>
 #include <sys/stat.h>
 #include <thread>
@@ -259,6 +261,27 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   if ((rc = mkdir_p(dir))) return raise(rc, __func__, product_dir);
 
   std::vector<Row> rows;
+  // rows are formatted off the main thread, one task per round; joined before the sort below
+  struct Job
+  {
+    int profile, seq, widx, wstart, wstop;
+    float lrt;
+    DcpHit hit;
+    std::vector<int32_t> ids, sizes;
+  };
+  std::deque<std::vector<Row>> formatted;
+  struct Joiner
+  {
+    std::vector<std::thread> threads;
+    void add(std::thread t) { threads.push_back(std::move(t)); }
+    void join()
+    {
+      for (std::thread &t : threads)
+        if (t.joinable()) t.join();
+      threads.clear();
+    }
+    ~Joiner() { join(); }
+  } formatters;
   Phase ph;
   int rounds = 0;
   size_t nwindows = 0, nhits = 0;
@@ -320,44 +343,52 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
         if ((rc = dcp_hip_path(x->eng, (int)(h1 - h0), hits.data() + h0)))
           return raise(rc, __func__, dcp_hip_strerror(x->eng));
         ph.path += ph.lap();
-        // hit spans first (they move the window chains), then the rows, formatted by up to
-        // 16 host threads (a row is a few thousand short appends)
-        struct Job { size_t h; DcpHit hit; std::vector<int32_t> ids, sizes; };
-        std::vector<Job> jobs;
+        // hit spans first (they move the window chains); the rows are then formatted by up to 16
+        // host threads (a row is a few thousand short appends) while the next round runs on the GPU
+        auto jobs = std::make_shared<std::vector<Job>>();
         for (size_t h = h0; h < h1; ++h)
         {
           int const n = dcp_hip_path_nsteps(x->eng, (int)(h - h0));
           Job j;
-          j.h = h;
           j.ids.resize((size_t)n);
           j.sizes.resize((size_t)n);
           if ((rc = dcp_hip_path_steps(x->eng, (int)(h - h0), j.ids.data(), j.sizes.data()))) return raise(rc, __func__);
           if (!dcp_find_hit(j.ids, j.sizes, j.hit)) continue;
-          pairs[owner[hit_of[h]]].win.last_hit_pos = j.hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
-          jobs.push_back(std::move(j));
+          Pair &pr = pairs[owner[hit_of[h]]];
+          pr.win.last_hit_pos = j.hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
+          j.profile = pr.profile;
+          j.seq = pr.seq;
+          j.widx = pr.win.idx;
+          j.wstart = pr.win.start;
+          j.wstop = pr.win.stop;
+          j.lrt = lrts[h];
+          jobs->push_back(std::move(j));
         }
-        size_t const base = rows.size();
-        rows.resize(base + jobs.size());
-        std::atomic<size_t> next_job{0};
-        auto work = [&]() {
-          for (size_t k = next_job.fetch_add(1); k < jobs.size(); k = next_job.fetch_add(1))
-          {
-            Job const &j = jobs[k];
-            Pair const &pr = pairs[owner[hit_of[j.h]]];
-            dcp_batch::Seq const &seq = batch->seqs[(size_t)pr.seq];
-            rows[base + k] = Row{pr.profile, pr.seq, pr.win.idx,
-                                 format_row(seq, pr.win.idx, pr.win.start, pr.win.stop, j.hit,
-                                            dcp_hip_profile_accession(x->eng, pr.profile), x->abc_name.c_str(),
-                                            lrts[j.h], j.ids, j.sizes)};
-          }
-        };
+        if (!jobs->empty())
         {
-          unsigned nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
-                                                  (unsigned)std::max<size_t>(jobs.size() / 8, 1)});
-          std::vector<std::thread> pool;
-          for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
-          work();
-          for (std::thread &t : pool) t.join();
+          formatted.emplace_back(jobs->size());
+          std::vector<Row> *out = &formatted.back();
+          dcp_scan const *scan = x;
+          formatters.add(std::thread([jobs, out, scan, batch]() {
+            std::atomic<size_t> next_job{0};
+            auto work = [&]() {
+              for (size_t k = next_job.fetch_add(1); k < jobs->size(); k = next_job.fetch_add(1))
+              {
+                Job const &j = (*jobs)[k];
+                dcp_batch::Seq const &seq = batch->seqs[(size_t)j.seq];
+                (*out)[k] = Row{j.profile, j.seq, j.widx,
+                                format_row(seq, j.widx, j.wstart, j.wstop, j.hit,
+                                           dcp_hip_profile_accession(scan->eng, j.profile), scan->abc_name.c_str(),
+                                           j.lrt, j.ids, j.sizes)};
+              }
+            };
+            unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
+                                                          (unsigned)std::max<size_t>(jobs->size() / 8, 1)});
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+            work();
+            for (std::thread &t : pool) t.join();
+          }));
         }
         h0 = h1;
         ph.rows += ph.lap();
@@ -369,6 +400,10 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     x->done_proteins += p1 - p0;
   }
 
+  formatters.join();
+  for (std::vector<Row> &part : formatted)
+    for (Row &r : part) rows.push_back(std::move(r));
+  ph.rows += ph.lap();
   // product_close (c-core/product.c:34-88): rows in profile, read, window order
   std::stable_sort(rows.begin(), rows.end(), [](Row const &a, Row const &b) {
     if (a.profile != b.profile) return a.profile < b.profile;
