@@ -482,6 +482,16 @@ static int push_profile(dcp_hip *x, HostProfile hp, std::vector<float> const &st
   return 0;
 }
 
+// The kernels take E_l = min_k M_l[k] (viterbi_body.h) and bound what a delete run can carry across a
+// wavefront (CostWave::row): both need the delete costs MD, DD to be non-negative, which -log-probabilities
+// are.  Anything else (a positive log-probability in a corrupt file, a hand-made table) is refused.
+static bool delete_costs_ok(float const *trans, int K, int Kp)
+{
+  for (int k = 0; k < K; ++k)
+    if (!(trans[(size_t)DCP_MD * Kp + k] >= 0.0f) || !(trans[(size_t)DCP_DD * Kp + k] >= 0.0f)) return false;
+  return true;
+}
+
 int dcp_hip_add_profile(struct dcp_hip *x, int K, float const *trans, float const *match, float const *null_cost,
                         float const *bg_cost, int *index)
 {
@@ -496,6 +506,7 @@ int dcp_hip_add_profile(struct dcp_hip *x, int K, float const *trans, float cons
   float *r = buf.data();
   float *t = r + (size_t)DCP_TABLE_SIZE * stride;
   for (int id = 0; id < DCP_NUM_TRANS; ++id) memcpy(t + (size_t)id * Kp, trans + (size_t)id * K, sizeof(float) * K);
+  if (!delete_costs_ok(t, K, Kp)) return fail(x, DCP_EFUNCUSE, "negative (or NaN) delete cost: costs are -log-probabilities");
   for (int c = 0; c < DCP_TABLE_SIZE; ++c)
   {
     float *hdr = r + (size_t)c * stride;
@@ -519,6 +530,7 @@ int dcp_hip_add_protein(struct dcp_hip *x, int K, float const *node_trans, float
   float *r = buf.data();
   float *t = r + (size_t)DCP_TABLE_SIZE * ((size_t)hp.Kp + DCP_ROW_HDR);
   dcp_setup_profile(K, hp.Kp, node_trans, node_emission, BMk, null_lprob, bg_lprob, t, r);
+  if (!delete_costs_ok(t, K, hp.Kp)) return fail(x, DCP_EFDATA, "positive (or NaN) delete log-probability in the protein");
   return push_profile(x, hp, buf, index);
 }
 
@@ -601,6 +613,11 @@ int dcp_hip_load_dcp(struct dcp_hip *x, char const *path, int first, int count)
         float *trans = rows + (size_t)DCP_TABLE_SIZE * ((size_t)hps[(size_t)i].Kp + DCP_ROW_HDR);
         dcp_setup_profile(p.core_size, hps[(size_t)i].Kp, p.trans.data(), p.emission.data(), p.BMk.data(),
                           p.null_emission.data(), p.bg_emission.data(), trans, rows);
+        if (!delete_costs_ok(trans, p.core_size, hps[(size_t)i].Kp))
+        {
+          int expected = 0;
+          bad.compare_exchange_strong(expected, DCP_EFDATA); // a positive delete log-probability
+        }
       }
     };
     {

@@ -47,7 +47,10 @@ char const *dcp_hip_strerror(struct dcp_hip const *); /* detail of the last fail
  * natural-log probabilities: node_trans[K+1][7] (MM,MI,MD,IM,II,DM,DD),
  * node_emission[K+1][1364], BMk[K], null/bg emission[1364], and applies the
  * mapping of protein_setup_viterbi (c-core/protein.c:353-394).
- * Both return the profile's index through *index. */
+ * Both return the profile's index through *index.  Core sizes up to 16383 (state ids keep 14
+ * bits for k + 1, c-core/state.h:27-39); DCP_ELARGECORESIZE beyond.  The delete costs MD, DD must
+ * be non-negative (-log-probabilities are): the kernels take E = min M and bound delete runs
+ * with that; DCP_EFUNCUSE / DCP_EFDATA otherwise. */
 int dcp_hip_add_profile(struct dcp_hip *, int K, float const *trans, float const *match,
                         float const *null_cost, float const *bg_cost, int *index);
 int dcp_hip_add_protein(struct dcp_hip *, int K, float const *node_trans, float const *node_emission,

@@ -278,6 +278,12 @@ def test_empty_and_invalid_calls(engine):
     with pytest.raises(deciphon_amd.HipError) as e:
         engine.cost([(0, 0, 0, 10 ** 7)])
     assert e.value.code == 8
+    # costs are -log-probabilities: a negative delete cost would break E = min M and is refused
+    bad = synth_profile(np.random.default_rng(1), 40)
+    bad.trans[7, 5] = np.float32(-0.5)
+    with pytest.raises(deciphon_amd.HipError) as e:
+        engine.add_profile(bad.K, bad.trans, bad.match, bad.null, bad.bg)
+    assert e.value.code == 8
 
 
 def test_full_size_config2_properties(engine, orc):
