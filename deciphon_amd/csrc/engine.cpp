@@ -174,6 +174,7 @@ struct dcp_hip
   // problems / results
   DevBuf<DcpProblem> d_problems;
   DevBuf<float> d_out;
+  DevBuf<int64_t> d_aux;           // strip class, literal path pass: table and scratch addresses per window
   DevBuf<float> d_ring;            // strip class (K > 4096): the rings of folded rows, one per workgroup in flight
   TableArena tables;               // DP tables of the fast path pass
   std::vector<int64_t> table_addr; // per window of the slice being staged (device addresses)
@@ -336,6 +337,7 @@ int launch_all(dcp_hip *x, Staged const &st, bool path)
   {
     DcpLaunch a = launch_args(x, st, c);
     if (a.nprob <= 0) continue;
+    if (path && c == DCP_STRIP_CLASS) continue; // replayed from the DP table instead (path_literal)
     if (fork)
     {
       a.stream = x->qstream[c];
@@ -971,17 +973,61 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
   if (n == 0) return 0;
   std::vector<dcp_hip_window> w((size_t)n);
   for (int j = 0; j < n; ++j) w[(size_t)j] = x->path_wins[(size_t)idx[(size_t)j]];
-  for (dcp_hip_window const &v : w)
-    if (x->profiles[(size_t)v.profile].cls == DCP_STRIP_CLASS)
-      return fail(x, DCP_ELARGECORESIZE,
-                  "the pass-by-pass path kernel (exact fp32 ties, packed trellis) stops at core size 4096; "
-                  "longer profiles have scores and tie-free paths only");
+  // Profiles beyond 4096 positions (strip class): the register-resident path kernel does not reach
+  // them; their trellis is replayed row by row from the DP table (row_replay.h).  Step 1, before
+  // the problem list below replaces this one on the device: the tables.
+  std::vector<int64_t> tab((size_t)n, 0), scr((size_t)n, 0);
+  int max_rows = 0;
+  {
+    std::vector<int> sl; // local indices of the strip-class windows
+    for (int j = 0; j < n; ++j)
+      if (x->profiles[(size_t)w[(size_t)j].profile].cls == DCP_STRIP_CLASS) sl.push_back(j);
+    if (!sl.empty())
+    {
+      std::vector<dcp_hip_window> ws(sl.size());
+      x->tables.reset();
+      x->table_addr.clear();
+      size_t const room = (size_t)1 << 40; // as much as the device gives: these windows are rare
+      for (size_t i = 0; i < sl.size(); ++i)
+      {
+        dcp_hip_window const &v = w[(size_t)sl[i]];
+        ws[i] = v;
+        HostProfile const &hp = x->profiles[(size_t)v.profile];
+        int const L = v.stop - v.start;
+        unsigned char *t = L >= 0 ? x->tables.place(table_bytes(L, hp.Kp), room) : nullptr;
+        unsigned char *a = t ? x->tables.place(((size_t)L + 1) * 3 * (size_t)hp.K * sizeof(float), room) : nullptr;
+        if (!t || !a) return fail(x, DCP_ENOMEM, "no device memory for the DP table of a long profile's path pass");
+        x->table_addr.push_back((int64_t)(uintptr_t)t);
+        tab[(size_t)sl[i]] = (int64_t)(uintptr_t)t;
+        scr[(size_t)sl[i]] = (int64_t)(uintptr_t)a;
+        max_rows = std::max(max_rows, L + 1);
+      }
+      Staged ss;
+      int rc0 = stage(x, (int)ws.size(), ws.data(), ARENA_TABLE, ss);
+      if (rc0) return rc0;
+      HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+      DcpLaunch a = launch_args(x, ss, DCP_STRIP_CLASS);
+      a.arena = nullptr;
+      HIP_TRY(x, dcp_launch_cost_store(DCP_STRIP_CLASS, a), DCP_EFUNCUSE);
+    }
+  }
   Staged st;
   int rc = stage(x, n, w.data(), ARENA_TRELLIS, st);
   if (rc) return rc;
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   HIP_TRY(x, x->d_trellis.reserve(st.arena_bytes), DCP_ENOMEM);
   if ((rc = launch_all(x, st, true))) return rc;
+  if (max_rows > 0) // step 2 for the strip class: the rows of every such window side by side
+  {
+    HIP_TRY(x, x->d_aux.reserve(2 * (size_t)n), DCP_ENOMEM);
+    HIP_TRY(x, hipMemcpyAsync(x->d_aux.p, tab.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, x->stream),
+            DCP_EFUNCUSE);
+    HIP_TRY(x, hipMemcpyAsync(x->d_aux.p + n, scr.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, x->stream),
+            DCP_EFUNCUSE);
+    DcpLaunch a = launch_args(x, st, DCP_STRIP_CLASS);
+    HIP_TRY(x, dcp_launch_replay(a, x->d_aux.p, x->d_aux.p + n, max_rows), DCP_EFUNCUSE);
+    HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE); // tab/scr are read by the copies above
+  }
 
   std::vector<int64_t> step_off = step_offsets(x, st, n);
   size_t const total_steps = (size_t)step_off[(size_t)n];

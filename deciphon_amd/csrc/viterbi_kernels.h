@@ -38,6 +38,8 @@ hipError_t dcp_launch_unzip(DcpLaunch const &a, uint32_t *steps, int64_t const *
 // traceback of every problem of a.problems (all classes) into steps / nsteps (as dcp_launch_unzip)
 hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a);
 hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps);
+// strip class: the trellis replayed row by row from the DP tables at table_addr[out] (scratch: 3*K floats per row)
+hipError_t dcp_launch_replay(DcpLaunch const &a, int64_t const *table_addr, int64_t const *scratch_addr, int max_rows);
 hipError_t dcp_launch_compact_steps(uint32_t const *steps, int64_t const *step_off, int64_t const *compact_off,
                                     uint32_t *out, int n, hipStream_t stream);
 // every problem of classes 0..3 (single-wave) in one launch

@@ -7,6 +7,7 @@
 #include "viterbi_body.h"
 #include "traceback.h"
 #include "viterbi_kernels.h"
+#include "row_replay.h"
 
 // (tried: holding Q = 3 / 4 to 96 / 128 VGPRs for 5 / 4 waves per SIMD -- the 6-7 scratch reloads per row cost
 // far more than the occupancy gives: 881 -> 620 GCUPS at K = 173, 1000 -> 878 at K = 256)
@@ -76,6 +77,53 @@ __global__ __launch_bounds__(64 * W) void dcp_strip_kernel(float const *__restri
     w.run(pb.L, out + 2 * (size_t)pb.out);
     __syncthreads(); // the next problem re-initialises the LDS records
   }
+}
+
+// The pass-by-pass trellis of profiles beyond 4096 positions: every row replayed from the DP table
+// by one thread (row_replay.h).  blockIdx.y = problem, blockIdx.x * 64 + threadIdx.x = row.
+__global__ __launch_bounds__(64) void dcp_replay_kernel(
+    float const *__restrict__ pool, DcpProfileDev const *__restrict__ profiles, DcpProblem const *__restrict__ problems,
+    DcpCodeRow const *__restrict__ code_rows, float const *__restrict__ xt_table, unsigned char *__restrict__ arena,
+    int64_t const *__restrict__ table_addr, int64_t const *__restrict__ scratch_addr, float *__restrict__ out, int nprob)
+{
+  int const p = (int)blockIdx.y;
+  if (p >= nprob) return;
+  DcpProblem const pb = problems[p];
+  int const l = (int)(blockIdx.x * 64u + threadIdx.x);
+  if (l > pb.L) return;
+  DcpProfileDev const pf = profiles[pb.profile];
+  uint32_t *xnodes = reinterpret_cast<uint32_t *>(arena + pb.trellis);
+  uint16_t *nodes = reinterpret_cast<uint16_t *>(xnodes + (pb.L + 1)) + (size_t)l * pf.K;
+  if (l == 0) // before(): every field 0 (c-core/viterbi.c:602-629)
+  {
+    xnodes[0] = 0;
+    for (int k = 0; k < pf.K; ++k) nodes[k] = 0;
+    return;
+  }
+  DcpTraceIn in;
+  in.K = pf.K;
+  in.Kp = pf.Kp;
+  in.L = pb.L;
+  in.sp = reinterpret_cast<float const *>((uintptr_t)table_addr[pb.out]);
+  in.cells = in.sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
+  in.rows = pool + pf.rows_off;
+  in.trans = pool + pf.trans_off;
+  in.codes = code_rows + pb.code_row;
+  in.xt = xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE;
+  float *acc = reinterpret_cast<float *>((uintptr_t)scratch_addr[pb.out]) + (size_t)l * 3 * pf.K;
+  dcp_replay_row(in, l, acc, xnodes + l, nodes);
+  if (l == pb.L) // T of the last row: the score viterbi_path returns (c-core/viterbi.c:585-586,599)
+    out[pb.out] = __builtin_fminf(in.sp[(size_t)l * DCP_SP_STRIDE + 3] + in.xt[DCP_ET],
+                                  in.sp[(size_t)l * DCP_SP_STRIDE + 4] + in.xt[DCP_CT]);
+}
+
+hipError_t dcp_launch_replay(DcpLaunch const &a, int64_t const *table_addr, int64_t const *scratch_addr, int max_rows)
+{
+  if (a.nprob <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dcp_replay_kernel, dim3((unsigned)((max_rows + 63) / 64), (unsigned)a.nprob), dim3(64), 0, a.stream,
+                     a.pool, a.profiles, a.problems, a.code_rows, a.xt_table, a.arena, table_addr, scratch_addr, a.out,
+                     a.nprob);
+  return hipGetLastError();
 }
 
 // Fast path pass, step 2: one WAVEFRONT walks one window's DP table back from T to S.

@@ -169,3 +169,26 @@ extern "C" int emul_strip_cost(float const *pool, DcpProfileDev const *pf, DcpCo
   default: return -1;
   }
 }
+
+// ---- the pass-by-pass trellis replayed row by row from the DP table (row_replay.h) ----
+#include "../../deciphon_amd/csrc/row_replay.h"
+#include <vector>
+extern "C" int emul_replay(float const *pool, DcpProfileDev const *pf, DcpCodeRow const *codes, int L,
+                           float const *xt, float const *cells, float const *sp, uint32_t *xnodes, uint16_t *nodes)
+{
+  DcpTraceIn in;
+  in.K = pf->K;
+  in.Kp = pf->Kp;
+  in.L = L;
+  in.sp = sp;
+  in.cells = cells;
+  in.rows = pool + pf->rows_off;
+  in.trans = pool + pf->trans_off;
+  in.codes = codes;
+  in.xt = xt;
+  std::vector<float> acc((size_t)3 * pf->K);
+  xnodes[0] = 0;
+  for (int k = 0; k < pf->K; ++k) nodes[k] = 0;
+  for (int l = 1; l <= L; ++l) dcp_replay_row(in, l, acc.data(), xnodes + l, nodes + (size_t)l * pf->K);
+  return 0;
+}

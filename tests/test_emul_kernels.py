@@ -201,3 +201,45 @@ def test_strip_mined_profiles(em, orc):
         else:
             assert n == -2, (it, K, n)
     assert nfallback > 0
+
+
+def test_rows_replayed_from_the_table_give_the_reference_trellis(em, orc):
+    """row_replay.h: with the DP table of the fast path pass, the trellis words of every row
+    can be recomputed on their own, pass by pass with the reference's strict-< updates.  Tie-rich
+    tables (every cost a multiple of 0.5..8), all kernel shapes incl. strips: every xnode and
+    node word against the oracle."""
+    rng = np.random.default_rng(29)
+    for it in range(150):
+        strips = 1
+        if it % 5 == 4:
+            Q, W, strips = [(1, 1, 3), (2, 2, 2), (1, 2, 3)][it % 3]
+            K = int(rng.integers(64 * Q * W * (strips - 1) + 1, 64 * Q * W * strips + 1))
+        else:
+            K = int(rng.choice([2, 3, 5, 8, 9, 16, 17, 33, 64, 65, 100, 173, 241, 256, 300, 400, 600]))
+            Q, W = choose_qw(K)
+        quant = [None, 0.5, 1.0, 2.0, 4.0, 8.0][it % 6]
+        prof = synth_profile(rng, K, quant, [0, 0.05, 0.3][it % 3])
+        seq = random_seq(rng, int(rng.integers(1, 40)))
+        L = len(seq)
+        xt = orc.xtrans(max(L // 3, 1), it % 2, (it // 2) % 2)
+        if quant:
+            xt = (np.round(xt / quant) * quant).astype(np.float32)
+        pool, pd = pack_profile(prof, Q, W, strips)
+        rows = code_rows(seq)
+        xt16 = np.zeros(16, np.float32)
+        xt16[:13] = xt
+        out = np.zeros(2, np.float32)
+        cells = np.full((L + 1) * 3 * pd.Kp, np.nan, np.float32)
+        sp = np.full((L + 1) * 8, np.nan, np.float32)
+        if strips > 1:
+            ring = np.zeros(10 * pd.Kp, np.float32)
+            assert em.emul_strip_cost(_vp(pool), C.byref(pd), _vp(rows), L, _vp(xt16), _vp(out), _vp(ring), _vp(cells), _vp(sp)) == 0
+        else:
+            assert em.emul_cost_store(_vp(pool), C.byref(pd), _vp(rows), L, _vp(xt16), _vp(out), _vp(cells), _vp(sp)) == 0
+        xn = np.full(L + 1, 0xFFFFFFFF, np.uint32)
+        nd = np.full((L + 1) * K, 0xFFFF, np.uint16)
+        assert em.emul_replay(_vp(pool), C.byref(pd), _vp(rows), L, _vp(xt16), _vp(cells), _vp(sp), _vp(xn), _vp(nd)) == 0
+        score, xo, no = orc.path(prof, xt, seq)
+        assert bits(out[1]) == bits(score)
+        assert np.array_equal(xn, xo), (it, K, quant)
+        assert np.array_equal(nd, no), (it, K, quant)

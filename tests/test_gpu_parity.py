@@ -219,8 +219,8 @@ def test_long_profiles_multi_wave_kernels(engine, orc):
 
 def test_profiles_beyond_4096_strip_by_strip(engine, orc):
     """K = 4097..16383: one workgroup walks every row in strips of 2048 positions with the
-    folded rows in HBM (StripWave).  Scores and the fast path pass against the oracle; the
-    pass-by-pass kernel does not cover this range, so a packed trellis is refused."""
+    folded rows in HBM (StripWave).  Scores, the fast path pass and the packed trellis (replayed
+    from the DP table) against the oracle."""
     import deciphon_amd
 
     rng = np.random.default_rng(53)
@@ -259,9 +259,46 @@ def test_profiles_beyond_4096_strip_by_strip(engine, orc):
         ids, sizes = orc.unzip(allp[pi].K, len(seq), xo, no)
         assert bits(paths[i]["score"]) == bits(score)
         assert np.array_equal(paths[i]["state_ids"], ids) and np.array_equal(paths[i]["seqsizes"], sizes), wins[i]
-    with pytest.raises(deciphon_amd.HipError) as e:
-        engine.path(wins[:1], trellis=True)
-    assert e.value.code == 63  # DCP_ELARGECORESIZE
+    # the packed trellis (and exact ties): replayed row by row from the DP table (row_replay.h)
+    sel = [wins[i] for i in (0, 3, 5, 10, 14, 19, len(wins) - 1)]
+    full = engine.path(sel, trellis=True)
+    for (pi, si, a, b), r in zip(sel, full):
+        seq = np.ascontiguousarray(seqs[si][a:b])
+        xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+        score, xo, no = orc.path(allp[pi], xt, seq)
+        assert bits(r["literal_score"]) == bits(score)
+        assert np.array_equal(r["xnodes"], xo) and np.array_equal(r["nodes"], no), (pi, si)
+        ids, sizes = orc.unzip(allp[pi].K, len(seq), xo, no)
+        assert np.array_equal(r["literal_state_ids"], ids) and np.array_equal(r["literal_seqsizes"], sizes)
+
+
+def test_ties_beyond_4096_go_through_the_row_replay(engine, orc):
+    """Quantised tables on K = 5000 and 9000: the fast pass gives up on exact ties and the
+    windows are redone from the DP table row by row -- same steps as the oracle."""
+    rng = np.random.default_rng(61)
+    profs = [synth_profile(rng, K, 2.0, 0.02) for K in (5000, 9000)]
+    seqs = [random_seq(rng, int(n)) for n in (6, 21, 33)]
+    engine.clear_profiles()
+    for p in profs:
+        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    engine.commit()
+    engine.set_sequences(seqs)
+    engine.set_mode(True, False)
+    smax = max(max(len(s) // 3, 1) for s in seqs)
+    table = np.zeros((smax + 1, 13), np.float32)
+    for s in range(1, smax + 1):
+        table[s] = synth_xt(orc, 3 * s, 1, 0, 2.0)
+    engine.set_xtrans_table(table)
+    wins = [(pi, si, 0, len(seqs[si])) for pi in range(len(profs)) for si in range(len(seqs))]
+    res = engine.path(wins, trellis=False)
+    assert engine.path_redone > 0
+    for (pi, si, a, b), r in zip(wins, res):
+        xt = synth_xt(orc, len(seqs[si]), 1, 0, 2.0)
+        score, xo, no = orc.path(profs[pi], xt, seqs[si])
+        ids, sizes = orc.unzip(profs[pi].K, len(seqs[si]), xo, no)
+        assert bits(r["score"]) == bits(score)
+        assert np.array_equal(r["state_ids"], ids) and np.array_equal(r["seqsizes"], sizes), (pi, si)
+    engine.set_xtrans_table(np.zeros((0, 13), np.float32))
 
 
 def test_empty_and_invalid_calls(engine):
