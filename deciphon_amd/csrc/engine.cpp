@@ -1065,6 +1065,9 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
     r.state_ids.clear();
     r.seqsizes.clear();
     int32_t const ns = nsteps[(size_t)p.out];
+    // a window with no finite path at all (score +inf) has no steps: the reference never walks such
+    // a trellis (process_window stops at a non-finite lrt, c-core/thread.c:118-121)
+    if (!(r.score < INFINITY)) continue;
     if (ns >= 0)
       unpack_steps(steps.data() + compact[(size_t)p.out], ns, r);
     else

@@ -108,7 +108,9 @@ int dcp_hip_cost(struct dcp_hip *, int n, struct dcp_hip_window const *, float *
  * the reference's strict-< rule); windows in which that meets an exact fp32 tie only the
  * reference's pass order resolves are redone with the literal pass-by-pass kernel.  The
  * trellis itself is produced (by the literal kernel, for the whole batch) only when
- * dcp_hip_path_trellis is called.  DECIPHON_HIP_PATH=literal forces the literal pass. */
+ * dcp_hip_path_trellis is called.  DECIPHON_HIP_PATH=literal forces the literal pass.
+ * A window with no finite path at all (viterbi_cost = +inf, which the reference never sends
+ * here: c-core/thread.c:118-121) yields 0 steps and score +inf. */
 int dcp_hip_path(struct dcp_hip *, int n, struct dcp_hip_window const *);
 /* how many windows of the last dcp_hip_path needed the literal pass */
 /* Sets aside `bytes` of HBM for the DP tables of dcp_hip_path now (never shrinks).  VRAM is

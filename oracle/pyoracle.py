@@ -115,13 +115,19 @@ class Oracle:
         return np.float32(score), xnodes, nodes
 
     def unzip(self, K: int, L: int, xnodes: np.ndarray, nodes: np.ndarray):
-        cap = 2 * L + 2 * K + 64  # delete runs: up to K mute steps
-        ids = np.empty(cap, dtype=np.int32)
-        sizes = np.empty(cap, dtype=np.int32)
-        n = self.lib.orc_unzip(K, L, xnodes, nodes, ids, sizes, cap)
-        if n < 0:
-            raise RuntimeError(f"orc_unzip failed ({n})")
-        return ids[:n].copy(), sizes[:n].copy()
+        # a path has at most L emitting steps, but every domain of a multi-hit path may run through up
+        # to K mute delete states: (L + 1) * (K + 4) bounds it; start small and grow on overflow (-1)
+        cap, limit = 2 * L + 2 * K + 64, (L + 1) * (K + 4) + 8
+        while True:
+            ids = np.empty(cap, dtype=np.int32)
+            sizes = np.empty(cap, dtype=np.int32)
+            n = self.lib.orc_unzip(K, L, xnodes, nodes, ids, sizes, cap)
+            if n == -1 and cap < limit:
+                cap = min(4 * cap, limit)
+                continue
+            if n < 0:
+                raise RuntimeError(f"orc_unzip failed ({n})")
+            return ids[:n].copy(), sizes[:n].copy()
 
     def lrt(self, null_loglik, alt_loglik) -> np.float32:
         return np.float32(self.lib.orc_lrt(float(null_loglik), float(alt_loglik)))

@@ -516,3 +516,33 @@ def test_path_pass_does_not_depend_on_call_history(engine, orc):
         for i, r in zip(order, res):
             assert np.array_equal(r["state_ids"], want[i][0]) and np.array_equal(r["seqsizes"], want[i][1]), (order, i)
     engine.set_xtrans_table(np.zeros((0, 13), np.float32))
+
+
+def test_window_without_any_finite_path(engine, orc):
+    """viterbi_cost = +inf (every way into the core is closed): the reference never walks such a
+    trellis (c-core/thread.c:118-121 stops at the non-finite lrt); dcp_hip_path gives 0 steps and
+    score +inf for it and is not disturbed in the windows around it."""
+    rng = np.random.default_rng(67)
+    closed = synth_profile(rng, 40, None, 0.0)
+    closed.trans[0, :] = np.float32(np.inf)  # BM: no entry
+    normal = synth_profile(rng, 40, None, 0.0)
+    seqs = [random_seq(rng, 30), random_seq(rng, 12)]
+    engine.clear_profiles()
+    for p in (normal, closed):
+        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    engine.commit()
+    engine.set_sequences(seqs)
+    engine.set_mode(True, False)
+    wins = [(0, 0, 0, 30), (1, 0, 0, 30), (1, 1, 0, 12), (0, 1, 0, 12)]
+    nul, alt = engine.cost(wins)
+    assert np.isinf(alt[1]) and np.isinf(alt[2]) and np.isfinite(alt[0]) and np.isfinite(alt[3])
+    res = engine.path(wins, trellis=False)
+    for i, (pi, si, a, b) in enumerate(wins):
+        xt = orc.xtrans(max(len(seqs[si]) // 3, 1), True, False)
+        score, xo, no = orc.path((normal, closed)[pi], xt, seqs[si])
+        assert bits(res[i]["score"]) == bits(score)
+        if pi == 1:
+            assert len(res[i]["state_ids"]) == 0 and np.isinf(res[i]["score"])
+        else:
+            ids, sizes = orc.unzip(40, len(seqs[si]), xo, no)
+            assert np.array_equal(res[i]["state_ids"], ids) and np.array_equal(res[i]["seqsizes"], sizes)
