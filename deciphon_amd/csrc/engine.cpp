@@ -782,12 +782,18 @@ int dcp_hip_cost(struct dcp_hip *x, int n, struct dcp_hip_window const *w, float
 {
   if (!x || (n > 0 && (!null_cost || !alt_cost))) return DCP_EFUNCUSE;
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  bool const timing = getenv("DECIPHON_HIP_TIMING") != nullptr && n > 1000;
+  auto const t0 = std::chrono::steady_clock::now();
   Staged st;
   int rc = stage(x, n, w, ARENA_NONE, st);
   if (rc) return rc;
   if (n == 0) return 0;
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  if (timing) (void)hipStreamSynchronize(x->stream);
+  auto const t1 = std::chrono::steady_clock::now();
   if ((rc = launch_cost_all(x, st))) return rc;
+  if (timing) (void)hipStreamSynchronize(x->stream);
+  auto const t2 = std::chrono::steady_clock::now();
   std::vector<float> out(2 * (size_t)n);
   HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
@@ -796,6 +802,13 @@ int dcp_hip_cost(struct dcp_hip *x, int n, struct dcp_hip_window const *w, float
   {
     null_cost[i] = out[2 * (size_t)i];
     alt_cost[i] = out[2 * (size_t)i + 1];
+  }
+  if (timing)
+  {
+    auto const t3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "dcp_hip_cost: %d windows; stage %.1f ms, kernels %.1f ms, fetch %.1f ms\n", n, ms(t0, t1), ms(t1, t2),
+            ms(t2, t3));
   }
   return 0;
 }

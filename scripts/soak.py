@@ -28,7 +28,7 @@ while time.time() - t0 < budget:
     profs = []
     for _ in range(nprof):
         u = rng.random()
-        K = int(rng.choice(edges)) if u < 0.4 else int(np.exp(rng.uniform(0, np.log(5000)))) if u < 0.9 else int(rng.integers(4097, 9000))
+        K = int(rng.choice(edges)) if u < 0.4 else int(np.exp(rng.uniform(0, np.log(5000)))) if u < 0.9 else int(rng.integers(4097, 16384))
         quant = [None, None, 0.5, 2.0, 8.0][int(rng.integers(0, 5))]
         p = synth_profile(rng, K, quant, float(rng.choice([0, 0.02, 0.2])))
         if K > 8 and rng.random() < 0.4:  # nearly free delete runs
@@ -51,8 +51,9 @@ while time.time() - t0 < budget:
             b = int(rng.integers(a + 1, len(r) + 1))
             wins.append((pi, si, a, b) if rng.random() < 0.5 else (pi, si, 0, len(r)))
     nul, alt = eng.cost(wins)
+    want_trellis = rng.random() < 0.3
     try:
-        paths = eng.path(wins, trellis=False)
+        paths = eng.path(wins, trellis=want_trellis)
     except deciphon_amd.HipError as e:
         print(f"ERROR seed={seed} round={rounds} mh={mh} h3={h3}: {e}", flush=True)
         for w in wins:
@@ -71,6 +72,8 @@ while time.time() - t0 < budget:
         ok = bits(nul[i]) == bits(orc.null(p, xt, seq)) and bits(alt[i]) == bits(orc.cost(p, xt, seq))
         score, xo, no = orc.path(p, xt, seq)
         ok = ok and bits(paths[i]["score"]) == bits(score)
+        if want_trellis:  # the packed trellis: the literal kernel, or the row replay beyond 4096
+            ok = ok and np.array_equal(paths[i]["xnodes"], xo) and np.array_equal(paths[i]["nodes"], no)
         if np.isfinite(score):
             try:
                 ids, sizes = orc.unzip(p.K, len(seq), xo, no)
