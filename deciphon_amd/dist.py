@@ -70,3 +70,49 @@ def gather_rows(rows, device="cpu"):
         if nrows:
             out += bytes(b[:nbytes].cpu().numpy()).decode().split("\n")
     return out
+
+
+PRODUCTS_HEADER = "sequence\twindow\twindow_start\twindow_stop\thit\thit_start\thit_stop\tprofile\tabc\tlrt\tevalue\tmatch"
+
+
+def scan_partitioned(dbfile, sequences, product_dir, multi_hits: bool = True, hmmer3_compat: bool = False,
+                     backend: str | None = None):
+    """One scan over all GPUs of the job (run under torchrun, one process per GPU): rank i scans the
+    i-th contiguous profile partition (c-core/partition_size.c:13-16 -- what thread i of
+    c-core/scan.c:188-208 would take) against all the reads; the product rows are gathered in
+    rank order, which is the reference's row order (c-core/product.c:63-81), and rank 0 writes
+    product_dir/products.tsv.  sequences: [(id, name, text)].  Returns all rows on every rank.
+
+    backend: "nccl" (RCCL; the default when every rank has its own GPU) or "gloo" (also lets several
+    ranks share one GPU, as the tests on a one-GPU box do)."""
+    import torch
+    import torch.distributed as dist
+
+    from .scan import Batch, Scan, Sequence
+
+    rank, local_rank, world = env_rank()
+    ndev = max(1, torch.cuda.device_count())
+    backend = backend or os.environ.get("DECIPHON_DIST_BACKEND") or ("nccl" if ndev >= world else "gloo")
+    device = local_rank % ndev
+    if world > 1 and not dist.is_initialized():
+        if backend == "nccl":
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
+    batch = Batch()
+    for sid, name, text in sequences:
+        batch.add(Sequence(sid, name, text))
+    part_dir = os.path.join(str(product_dir), f"part{rank}")
+    with Scan(dbfile, 0, 1, multi_hits, hmmer3_compat, False, partition=(device, rank, world)) as scan:
+        scan.run(part_dir, batch)
+        rows = scan.products()
+    rows = gather_rows(rows, f"cuda:{device}" if backend == "nccl" and world > 1 else "cpu")
+    if rank == 0:
+        with open(os.path.join(str(product_dir), "products.tsv"), "w") as f:
+            f.write(PRODUCTS_HEADER + "\n")
+            for r in rows:
+                f.write(r + "\n")
+    if world > 1:
+        dist.barrier()
+    return rows

@@ -177,3 +177,25 @@ def test_errors_and_interrupt(tmp_path):
     with scan:
         scan.run(str(tmp_path), b)
         assert len(calls) == 3  # one callback per window: 3 profiles x 1 read x 1 window
+
+
+def test_two_ranks_scan_their_partitions_and_gather(tmp_path):
+    """deciphon_amd.dist.scan_partitioned under torchrun with 2 ranks (both on this box's one GPU,
+    rows gathered over gloo): the gathered products.tsv equals the single-process scan's."""
+    import subprocess
+    import sys
+
+    from dcp_testlib import ROOT
+
+    reads = read_fasta(os.path.join(GOLDEN, "consensus_multi.fna"))
+    fasta = tmp_path / "reads.fna"
+    fasta.write_text("".join(f">r{i}\n{t}\n" for i, (_, t) in enumerate(reads)))
+    single = run_scan(str(tmp_path / "single"), [(i, t) for i, (_, t) in enumerate(reads)])
+    env = dict(os.environ, DECIPHON_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(ROOT, "scripts", "scan_multi_gpu.py"), DCP, str(fasta), str(tmp_path / "multi")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = (tmp_path / "multi" / "products.tsv").read_text().splitlines()
+    assert lines[1:] == single and len(single) > 0
