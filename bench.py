@@ -139,7 +139,14 @@ def main():
 
     rank, local_rank, world = ddist.init_process_group("cuda")
     dist = torch.distributed if world > 1 else None
+    # one rank per GPU; the modulo only matters when a multi-rank run is rehearsed on fewer GPUs
+    # (DECIPHON_DIST_BACKEND=gloo), where ranks share a device
+    local_rank %= max(1, torch.cuda.device_count())
     dev = f"cuda:{local_rank}"
+    if os.environ.get("DECIPHON_DIST_BACKEND") == "gloo":
+        dev_coll = "cpu"
+    else:
+        dev_coll = dev
 
     dcp = os.path.join(GOLDEN, "minifam.dcp")
     db = read_dcp(dcp)
@@ -168,8 +175,8 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
 
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    c = torch.tensor([cells], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall], dtype=torch.float64, device=dev_coll)
+    c = torch.tensor([cells], dtype=torch.float64, device=dev_coll)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
@@ -190,7 +197,7 @@ def main():
     nul, alt = eng.fetch_staged()
     lrt = -2.0 * ((-nul) - (-alt))
     rows = [f"{rank}\t{wins[i][0]}\t{wins[i][1]}\t{lrt[i]:.1f}" for i in np.nonzero(lrt >= 0)[0]]
-    all_rows = ddist.gather_rows(rows, dev)
+    all_rows = ddist.gather_rows(rows, dev_coll)
 
     if rank == 0:
         gcups = total_cells * args.steps / t_max / 1e9

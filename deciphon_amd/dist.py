@@ -37,7 +37,9 @@ def init_process_group(device=None):
     rank, local_rank, world = env_rank()
     if world <= 1 or dist.is_initialized():
         return rank, local_rank, world
-    if device is not None and str(device).startswith("cuda"):
+    # DECIPHON_DIST_BACKEND=gloo: rehearsal of a multi-rank job on a box with fewer GPUs than ranks
+    backend = os.environ.get("DECIPHON_DIST_BACKEND")
+    if device is not None and str(device).startswith("cuda") and backend != "gloo":
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
