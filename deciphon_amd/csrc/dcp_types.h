@@ -22,8 +22,8 @@ struct DcpCodeRow
 };
 
 #define DCP_SP_STRIDE 8 // floats per row of special-state values in a DP table: N,B,J,E,C,0,0,0
-#define DCP_ROW_HDR 4
-#define DCP_MAX_STRIPS 8 // K > 4096: strips of 2048 positions (StripWave), up to 16384 padded positions // floats in front of every emission row: null[c], bg[c], 0, 0
+#define DCP_ROW_HDR 4    // floats in front of every emission row: null[c], bg[c], 0, 0
+#define DCP_MAX_STRIPS 8 // K > 4096: strips of 2048 positions (StripWave), up to 16384 padded positions
 
 // A profile resident in HBM, in DP-parameter space (costs = -log-prob, +inf =
 // impossible), padded to Kp = 64*Q*W positions with +inf.  All arrays live in

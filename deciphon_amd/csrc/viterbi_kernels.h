@@ -3,8 +3,11 @@
 #include "dcp_types.h"
 #include <hip/hip_runtime.h>
 
-// kernel classes (Q positions per lane, W wavefronts per problem):
-//   0..3: (1..4, 1) K <= 64..256;  4..7: (4, 2/4/8/16) K <= 512/1024/2048/4096
+// kernel classes by padded size Kp (dcp_class_of / dcp_class_shape in viterbi_kernels.hip):
+//   0..3: Kp = 64..256, one wavefront, 1..4 positions per lane
+//   4..10: Kp = 384, 512, 768, 1024, 1536, 2048, 4096; cost kernels (6,1) (8,1) (6,2) (4,4) (6,4) (8,4) (8,8),
+//          pass-by-pass path kernel (3,2) (4,2) (3,4) (4,4) (3,8) (4,8) (4,16)
+//   11:    4096 < K <= 16383, strip by strip
 #define DCP_NUM_CLASSES 12
 #define DCP_STRIP_CLASS 11      // K > 4096: strips of DCP_STRIP_POSITIONS, state ring in HBM (StripWave)
 #define DCP_STRIP_POSITIONS 2048 // 64 lanes x 4 positions x 8 wavefronts
