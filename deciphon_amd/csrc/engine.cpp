@@ -1128,11 +1128,30 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
   if (rc) return rc;
   tm.lap("stage");
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
-  for (int c = 0; c < DCP_NUM_CLASSES; ++c)
   {
-    DcpLaunch a = launch_args(x, st, c);
-    a.arena = nullptr; // DcpProblem::trellis holds the table's address
-    HIP_TRY(x, dcp_launch_cost_store(c, a), DCP_EFUNCUSE);
+    // the classes of a slice are each too small to fill the GPU and each lasts as long as its longest
+    // window: they go out on their own streams, forked from and joined back into x->stream
+    int classes = 0;
+    for (int c = 0; c < DCP_NUM_CLASSES; ++c) classes += st.c_begin[c + 1] > st.c_begin[c];
+    bool const fork = classes > 1;
+    if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
+    for (int c = 0; c < DCP_NUM_CLASSES; ++c)
+    {
+      DcpLaunch a = launch_args(x, st, c);
+      if (a.nprob <= 0) continue;
+      a.arena = nullptr; // DcpProblem::trellis holds the table's address
+      if (fork)
+      {
+        a.stream = x->qstream[c];
+        HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
+      }
+      HIP_TRY(x, dcp_launch_cost_store(c, a), DCP_EFUNCUSE);
+      if (fork)
+      {
+        HIP_TRY(x, hipEventRecord(x->join_ev[c], a.stream), DCP_EFUNCUSE);
+        HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
+      }
+    }
   }
   tm.lap("cost+store");
   std::vector<int64_t> step_off = step_offsets(x, st, n);
