@@ -362,13 +362,22 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
   int mixed = 0;
   for (int c = 0; c < 4; ++c) mixed += st.c_begin[c + 1] > st.c_begin[c];
   if (mixed < 2 || single_wave > 16384) return launch_all(x, st, false);
+  // the other classes of a small launch run beside the fused kernel, on their own streams
+  bool fork = false;
+  for (int c = 4; c < DCP_NUM_CLASSES; ++c) fork = fork || st.c_begin[c + 1] > st.c_begin[c];
+  if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
   DcpLaunch a = launch_args(x, st, 0);
   a.nprob = single_wave;
   HIP_TRY(x, dcp_launch_cost_fused(a), DCP_EFUNCUSE);
   for (int c = 4; c < DCP_NUM_CLASSES; ++c)
   {
     DcpLaunch b = launch_args(x, st, c);
+    if (b.nprob <= 0) continue;
+    b.stream = x->qstream[c];
+    HIP_TRY(x, hipStreamWaitEvent(b.stream, x->fork_ev, 0), DCP_EFUNCUSE);
     HIP_TRY(x, dcp_launch_cost(c, b), DCP_EFUNCUSE);
+    HIP_TRY(x, hipEventRecord(x->join_ev[c], b.stream), DCP_EFUNCUSE);
+    HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
   }
   return 0;
 }
