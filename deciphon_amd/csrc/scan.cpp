@@ -415,10 +415,11 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   if (!fp) return raise(DCP_EFOPEN, __func__, file.c_str());
   bool ok = fputs("sequence\twindow\twindow_start\twindow_stop\thit\thit_start\thit_stop\tprofile\tabc\tlrt\tevalue\tmatch\n",
                   fp) >= 0;
-  for (Row const &r : rows)
+  x->products.reserve(rows.size());
+  for (Row &r : rows)
   {
-    ok = ok && fputs(r.text.c_str(), fp) >= 0 && fputc('\n', fp) != EOF;
-    x->products.push_back(r.text);
+    ok = ok && fwrite(r.text.data(), 1, r.text.size(), fp) == r.text.size() && fputc('\n', fp) != EOF;
+    x->products.push_back(std::move(r.text));
   }
   if (fclose(fp) != 0 || !ok) return raise(DCP_EWRITEPROD, __func__, file.c_str());
   ph.write += ph.lap();
