@@ -1288,6 +1288,12 @@ int dcp_hip_path_reserve(struct dcp_hip *x, int64_t bytes)
 {
   if (!x || bytes < 0) return DCP_EFUNCUSE;
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  {
+    // never more than a quarter of what is free right now: several scans may share the device
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)bytes > x->tables.held + free_b / 4)
+      bytes = (int64_t)(x->tables.held + free_b / 4);
+  }
   x->tables.reset();
   // place() allocates chunk after chunk until the arena holds `bytes`
   while (x->tables.held < (size_t)bytes)

@@ -115,7 +115,8 @@ int dcp_hip_path(struct dcp_hip *, int n, struct dcp_hip_window const *);
 /* how many windows of the last dcp_hip_path needed the literal pass */
 /* Sets aside `bytes` of HBM for the DP tables of dcp_hip_path now (never shrinks).  VRAM is
  * cleared when allocated, in the background: called early (before the profiles are loaded) the
- * clearing overlaps the load and the cost pass.  Optional: dcp_hip_path allocates on demand. */
+ * clearing overlaps the load and the cost pass.  Clamped to a quarter of the free device memory.
+ * Optional: dcp_hip_path allocates on demand. */
 int dcp_hip_path_reserve(struct dcp_hip *, int64_t bytes);
 int dcp_hip_path_redone(struct dcp_hip const *);
 /* number of steps of window i's path (S ... T) */
