@@ -109,17 +109,20 @@ Tok next(Cur &c)
   return t;
 }
 
-// skips one complete value
+// skips one complete value.  Iterative, with a count of values still owed: a file of nested
+// array headers cannot take the stack, it just runs into the end of the buffer.
 bool skip(Cur &c)
 {
-  Tok t = next(c);
-  if (t.kind == K_BAD) return false;
-  if (t.kind == K_ARRAY)
-    for (int64_t i = 0; i < t.i; ++i)
-      if (!skip(c)) return false;
-  if (t.kind == K_MAP)
-    for (int64_t i = 0; i < 2 * t.i; ++i)
-      if (!skip(c)) return false;
+  uint64_t pending = 1;
+  while (pending)
+  {
+    Tok t = next(c);
+    if (t.kind == K_BAD) return false;
+    --pending;
+    uint64_t const more = t.kind == K_ARRAY ? (uint64_t)t.i : t.kind == K_MAP ? 2 * (uint64_t)t.i : 0;
+    if (more > (uint64_t)1 << 40) return false; // no .dcp value holds that many items
+    pending += more;
+  }
   return true;
 }
 

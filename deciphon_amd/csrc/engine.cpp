@@ -1236,6 +1236,15 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
   x->host_trellis.assign((size_t)n, std::vector<unsigned char>());
   if (n == 0) return 0;
   std::vector<int> redo;
+  // every window is checked here, whichever pass takes it (path_literal indexes x->profiles before stage() looks)
+  int const nseq = (int)x->seq_off.size() - 1;
+  for (int i = 0; i < n; ++i)
+  {
+    if (w[i].profile < 0 || w[i].profile >= (int)x->profiles.size()) return fail(x, DCP_EFUNCUSE, "bad profile index");
+    if (w[i].seq < 0 || w[i].seq >= nseq) return fail(x, DCP_EFUNCUSE, "bad sequence index");
+    int64_t const len = x->seq_off[(size_t)w[i].seq + 1] - x->seq_off[(size_t)w[i].seq];
+    if (w[i].start < 0 || w[i].stop < w[i].start || w[i].stop > len) return fail(x, DCP_EFUNCUSE, "bad window range");
+  }
   char const *mode = getenv("DECIPHON_HIP_PATH"); // "literal": skip the fast pass (tests, debugging)
   if (mode && strcmp(mode, "literal") == 0)
     for (int i = 0; i < n; ++i) redo.push_back(i);
@@ -1246,8 +1255,6 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
     std::vector<double> cost((size_t)n);
     for (int i = 0; i < n; ++i)
     {
-      if (w[i].profile < 0 || w[i].profile >= (int)x->profiles.size()) return fail(x, DCP_EFUNCUSE, "bad profile index");
-      if (w[i].stop < w[i].start) return fail(x, DCP_EFUNCUSE, "bad window range");
       int const W = x->profiles[(size_t)w[i].profile].W;
       cost[(size_t)i] = (double)(w[i].stop - w[i].start) * (W == 1 ? 1.0 : W == 2 ? 2.0 : W == 4 ? 2.5 : W == 8 ? 3.0 : 4.0);
     }

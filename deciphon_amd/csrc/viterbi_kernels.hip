@@ -79,16 +79,13 @@ __global__ __launch_bounds__(64 * W) void dcp_strip_kernel(float const *__restri
   }
 }
 
-// The pass-by-pass trellis of profiles beyond 4096 positions: every row replayed from the DP table
-// by one thread (row_replay.h).  blockIdx.y = problem, blockIdx.x * 64 + threadIdx.x = row.
-__global__ __launch_bounds__(64) void dcp_replay_kernel(
-    float const *__restrict__ pool, DcpProfileDev const *__restrict__ profiles, DcpProblem const *__restrict__ problems,
-    DcpCodeRow const *__restrict__ code_rows, float const *__restrict__ xt_table, unsigned char *__restrict__ arena,
-    int64_t const *__restrict__ table_addr, int64_t const *__restrict__ scratch_addr, float *__restrict__ out, int nprob)
+// one row of one window's trellis
+__device__ void dcp_replay_one(float const *__restrict__ pool, DcpProfileDev const *__restrict__ profiles,
+                               DcpProblem const pb, DcpCodeRow const *__restrict__ code_rows,
+                               float const *__restrict__ xt_table, unsigned char *__restrict__ arena,
+                               int64_t const *__restrict__ table_addr, int64_t const *__restrict__ scratch_addr,
+                               float *__restrict__ out)
 {
-  int const p = (int)blockIdx.y;
-  if (p >= nprob) return;
-  DcpProblem const pb = problems[p];
   int const l = (int)(blockIdx.x * 64u + threadIdx.x);
   if (l > pb.L) return;
   DcpProfileDev const pf = profiles[pb.profile];
@@ -117,10 +114,22 @@ __global__ __launch_bounds__(64) void dcp_replay_kernel(
                                   in.sp[(size_t)l * DCP_SP_STRIDE + 4] + in.xt[DCP_CT]);
 }
 
+// The pass-by-pass trellis of profiles beyond 4096 positions: every row replayed from the DP table
+// by one thread (row_replay.h).  blockIdx.y (strided: the y extent of a grid stops at 65535) = problem,
+// blockIdx.x * 64 + threadIdx.x = row.
+__global__ __launch_bounds__(64) void dcp_replay_kernel(
+    float const *__restrict__ pool, DcpProfileDev const *__restrict__ profiles, DcpProblem const *__restrict__ problems,
+    DcpCodeRow const *__restrict__ code_rows, float const *__restrict__ xt_table, unsigned char *__restrict__ arena,
+    int64_t const *__restrict__ table_addr, int64_t const *__restrict__ scratch_addr, float *__restrict__ out, int nprob)
+{
+  for (int p = (int)blockIdx.y; p < nprob; p += (int)gridDim.y)
+    dcp_replay_one(pool, profiles, problems[p], code_rows, xt_table, arena, table_addr, scratch_addr, out);
+}
+
 hipError_t dcp_launch_replay(DcpLaunch const &a, int64_t const *table_addr, int64_t const *scratch_addr, int max_rows)
 {
   if (a.nprob <= 0) return hipSuccess;
-  hipLaunchKernelGGL(dcp_replay_kernel, dim3((unsigned)((max_rows + 63) / 64), (unsigned)a.nprob), dim3(64), 0, a.stream,
+  hipLaunchKernelGGL(dcp_replay_kernel, dim3((unsigned)((max_rows + 63) / 64), (unsigned)(a.nprob < 65535 ? a.nprob : 65535)), dim3(64), 0, a.stream,
                      a.pool, a.profiles, a.problems, a.code_rows, a.xt_table, a.arena, table_addr, scratch_addr, a.out,
                      a.nprob);
   return hipGetLastError();
@@ -371,27 +380,29 @@ __global__ __launch_bounds__(64 * W) void dcp_path_kernel(float const *__restric
 __global__ void dcp_encode_kernel(unsigned char const *__restrict__ nt, int64_t const *__restrict__ seq_off,
                                   int64_t const *__restrict__ row_off, int nseq, DcpCodeRow *__restrict__ rows)
 {
-  int const s = (int)blockIdx.y;
-  if (s >= nseq) return;
-  int64_t const n = seq_off[s + 1] - seq_off[s];
-  unsigned char const *x = nt + seq_off[s];
-  DcpCodeRow *out = rows + row_off[s];
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += (int64_t)gridDim.x * blockDim.x)
+  // gridDim.y is capped at 65535 (a batch of metagenomic reads is larger): stride over the sequences
+  for (int s = (int)blockIdx.y; s < nseq; s += (int)gridDim.y)
   {
-    DcpCodeRow cr;
-    unsigned const off[5] = {0u, 4u, 20u, 84u, 340u};
-    unsigned idx = 0;
-#pragma unroll
-    for (int t = 1; t <= 5; ++t)
+    int64_t const n = seq_off[s + 1] - seq_off[s];
+    unsigned char const *x = nt + seq_off[s];
+    DcpCodeRow *out = rows + row_off[s];
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += (int64_t)gridDim.x * blockDim.x)
     {
-      // extend the t-mer to the left: new symbol is the most significant digit
-      bool const ok = r - t >= 0;
-      unsigned const sym = ok ? x[r - t] : 0u;
-      idx += sym << (2 * (t - 1));
-      cr.c[t - 1] = ok ? off[t - 1] + idx : 0u;
+      DcpCodeRow cr;
+      unsigned const off[5] = {0u, 4u, 20u, 84u, 340u};
+      unsigned idx = 0;
+#pragma unroll
+      for (int t = 1; t <= 5; ++t)
+      {
+        // extend the t-mer to the left: new symbol is the most significant digit
+        bool const ok = r - t >= 0;
+        unsigned const sym = ok ? x[r - t] : 0u;
+        idx += sym << (2 * (t - 1));
+        cr.c[t - 1] = ok ? off[t - 1] + idx : 0u;
+      }
+      cr.c[5] = cr.c[6] = cr.c[7] = 0;
+      out[r] = cr;
     }
-    cr.c[5] = cr.c[6] = cr.c[7] = 0;
-    out[r] = cr;
   }
 }
 
@@ -659,7 +670,7 @@ hipError_t dcp_launch_encode(unsigned char const *nt, int64_t const *seq_off, in
   unsigned bx = (unsigned)((max_len + 1 + 255) / 256);
   if (bx < 1) bx = 1;
   if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(dcp_encode_kernel, dim3(bx, (unsigned)nseq), dim3(256), 0, stream, nt, seq_off, row_off, nseq,
-                     rows);
+  hipLaunchKernelGGL(dcp_encode_kernel, dim3(bx, (unsigned)(nseq < 65535 ? nseq : 65535)), dim3(256), 0, stream, nt,
+                     seq_off, row_off, nseq, rows);
   return hipGetLastError();
 }

@@ -281,9 +281,12 @@ class Engine:
         for i in range(n):
             xn, nd = C.c_void_p(), C.c_void_p()
             self._check(self.lib.dcp_hip_path_trellis(self.h, i, C.byref(xn), C.byref(nd)))
-            w = arr[i]
-            L = w.stop - w.start
-            K = self.core_size(w.profile)
+            if isinstance(windows, np.ndarray):  # arr is then a bare pointer to the int32 [n][4] array
+                prof, _, start, stop = (int(v) for v in np.asarray(windows, dtype=np.int32).reshape(-1, 4)[i])
+            else:
+                prof, start, stop = arr[i].profile, arr[i].start, arr[i].stop
+            L = stop - start
+            K = self.core_size(prof)
             out[i]["xnodes"] = np.ctypeslib.as_array(C.cast(xn, C.POINTER(C.c_uint32)), shape=(L + 1,)).copy()
             out[i]["nodes"] = np.ctypeslib.as_array(C.cast(nd, C.POINTER(C.c_uint16)), shape=((L + 1) * K,)).copy()
             # the literal pass has replaced the steps: they must be the very same path

@@ -55,6 +55,9 @@ void dcp_press_del(struct dcp_press const *);
 
 char const *dcp_error_string(int error_code);
 
+/* the DCP_E* return codes, c-core/deciphon.h:34-116 */
+#include "deciphon_errors.h"
+
 /* Not in the reference: a scan that owns only partition `index` of `nparts`
  * contiguous profile partitions (partition_size, c-core/partition_size.c:13-16) on
  * HIP device `device` -- what one rank of a multi-GPU job calls instead of

@@ -48,6 +48,20 @@ int main(int argc, char **argv)
     rc = dcp_db_open(argv[2], &db);
     if (!rc) { int m = dcp_db_num_proteins(db); for (int i = 0; i < m && i < 3; ++i) { int K; if (!dcp_db_protein_core_size(db, i, &K) && K > 0 && K < 100000) { float *em = (float *)malloc((size_t)(K + 1) * 1364 * 4); float *tr = (float *)malloc((size_t)(K + 1) * 7 * 4); float *bm = (float *)malloc((size_t)K * 4); char *cons = (char *)malloc(K + 1); char acc[32]; (void)dcp_db_read_protein(db, i, tr, em, bm, 0, 0, acc, cons); free(em); free(tr); free(bm); free(cons); } } dcp_db_close(db); }
   }
+  {
+    /* a value nested a few hundred thousand arrays deep behind the first "idx" key (skipped by the reader):
+     * must fail with an error code, not overflow the stack */
+    char const key[] = {(char)0xa3, 'i', 'd', 'x'};
+    long at = -1;
+    for (long i = 0; i + 4 < sz && i < 4096; ++i) if (!memcmp(buf + i, key, 4)) { at = i + 4; break; }
+    if (at < 0) { printf("no idx key\n"); return 1; }
+    long const deep = 400000;
+    char *c2 = (char *)malloc(at + deep); memcpy(c2, buf, at); memset(c2 + at, 0x91, deep);
+    f = fopen(argv[2], "wb"); fwrite(c2, 1, at + deep, f); fclose(f); free(c2);
+    rc = dcp_db_open(argv[2], &db);
+    printf("  nested arrays: rc %d\n", rc);
+    if (!rc) { printf("nested arrays accepted\n"); return 1; }
+  }
   printf("fuzz done\n");
   free(buf);
   return 0;

@@ -56,6 +56,12 @@ int main(int argc, char **argv)
 
   struct dcp_scan *scan = dcp_scan_new();
   if (!scan) return 1;
+  /* the error codes are part of the public header (c-core/deciphon.h:34-116) */
+  if (dcp_scan_setup(scan, "/nonexistent/none.dcp", 51300, 1, true, false, false, NULL, NULL) != DCP_EOPENDB)
+  {
+    fprintf(stderr, "a missing database must fail with DCP_EOPENDB\n");
+    return 1;
+  }
   if ((rc = dcp_scan_setup(scan, argv[1], 51300, 1, multi_hits, hmmer3_compat, false, on_window, NULL)))
   {
     fprintf(stderr, "dcp_scan_setup: %s\n", dcp_error_string(rc));
