@@ -1,0 +1,237 @@
+"""Synthetic workloads in the reference's own data formats: Pfam-shaped pressed databases
+built by resampling the nodes of a seed database, reads with planted error-bearing domains,
+and a `.dcp` writer for both array encodings found in the wild.
+
+Pfam-A itself is not available offline (SURVEY 8d config 4 names this fallback): a profile
+here is a chain of node runs cut out of the seed proteins (control/tests/files/minifam.dcp in
+the tests and the benchmark), so its emission tables, transitions and entry costs have the
+values and the structure of real pressed profiles; only the lengths are drawn, from a
+log-normal fitted to Pfam-A's model lengths (median 140, mean ~173, tail to 2500).
+
+`.dcp` schema: c-core/database_writer.c:95-193 (header, protein_sizes), c-core/protein.c:234-281
+(protein_pack), c-core/write.c:59-66 (f32 arrays as `bin`); the legacy encoding is the one of
+the reference's committed fixture (f32 arrays as big-endian `ext` type 8, protein_sizes as one
+`ext` type 6: SURVEY Appendix A).  No third-party msgpack module: the few MessagePack forms the
+format needs are emitted here.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+TABLE_SIZE = 1364
+AMINO = "ACDEFGHIKLMNPQRSTVWY"
+# one fixed codon per amino acid, to back-translate a consensus into a plantable domain
+CODON = dict(zip(AMINO, ["GCT", "TGT", "GAT", "GAA", "TTT", "GGT", "CAT", "ATT", "AAA", "CTG", "ATG", "AAT", "CCT",
+                         "CAA", "CGT", "TCT", "ACT", "GTT", "TGG", "TAT"]))
+_NT = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+# ---- profiles ------------------------------------------------------------------------------
+
+def pfam_like_lengths(n: int, seed: int, lo: int = 10, hi: int = 2500) -> np.ndarray:
+    """n core sizes from a log-normal (median 140, sigma 0.65: mean ~173), clipped to [lo, hi]."""
+    rng = np.random.default_rng(seed)
+    return np.clip(np.exp(rng.normal(np.log(140.0), 0.65, size=n)).astype(np.int64), lo, hi)
+
+
+def _finish(K, src, seeds, accession):
+    """src[K] = (seed protein, node) per position -> a protein dict in protein_unpack's layout."""
+    emission = np.empty((K + 1, TABLE_SIZE), np.float32)
+    trans = np.empty((K + 1, 7), np.float32)
+    BMk = np.empty(K, np.float32)
+    cons = []
+    for k, (p, i) in enumerate(src):
+        s = seeds[p]
+        emission[k] = s["emission"][i]
+        trans[k] = s["trans"][i]
+        BMk[k] = s["BMk"][i]
+        cons.append(s["consensus"][i] if i < len(s["consensus"]) else "x")
+    # the end of a model as the reference builds it (c-core/model.c; visible in any pressed profile):
+    # node K duplicates node K-1, whose MD and DD are impossible and whose DM is certain
+    emission[K] = emission[K - 1]
+    trans[K - 1, 2] = trans[K - 1, 6] = -np.inf
+    trans[K - 1, 5] = 0.0
+    trans[K] = trans[K - 1]
+    s0 = seeds[src[0][0]]
+    return dict(core_size=K, accession=accession, gencode=1, consensus="".join(cons), trans=trans,
+                emission=emission, BMk=BMk, null_emission=np.array(s0["null_emission"], np.float32),
+                bg_emission=np.array(s0["bg_emission"], np.float32))
+
+
+def resample_protein(seeds, K: int, rng, accession: str, mean_run: int = 30) -> dict:
+    """A protein of K nodes made of runs of consecutive interior nodes of the seed proteins."""
+    src = []
+    while len(src) < K:
+        p = int(rng.integers(0, len(seeds)))
+        Ks = seeds[p]["core_size"]
+        run = int(min(rng.geometric(1.0 / mean_run), K - len(src), max(Ks - 2, 1)))
+        i0 = int(rng.integers(0, max(Ks - 1 - run, 0) + 1))
+        src += [(p, i0 + j) for j in range(run)]
+    return _finish(K, src, seeds, accession)
+
+
+def tile_protein(seeds, K: int, offset: int, accession: str) -> dict:
+    """A protein of K nodes: the interior nodes of the seed proteins one after the other, cyclically,
+    starting `offset` nodes in (deterministic: the long profiles of SURVEY 8d config 3b)."""
+    ring = [(p, i) for p, s in enumerate(seeds) for i in range(s["core_size"] - 1)]
+    src = [ring[(offset + k) % len(ring)] for k in range(K)]
+    return _finish(K, src, seeds, accession)
+
+
+def load_seeds(path: str):
+    """Every protein of a pressed database, through the product's own reader."""
+    from .host import Database
+
+    db = Database(path)
+    seeds = [db.protein(i) for i in range(len(db))]
+    db.close()
+    return seeds
+
+
+def pfam_like_database(seeds, n: int, seed: int, first: int = 0, lengths=None):
+    """Proteins first..first+n-1 of the (conceptually endless) Pfam-shaped database `seed`: protein i
+    depends on (seed, i) only, so partitions can be generated independently of each other."""
+    Ks = pfam_like_lengths(first + n, seed)[first:] if lengths is None else lengths
+    out = []
+    for j, K in enumerate(Ks):
+        i = first + j
+        rng = np.random.default_rng([seed, i])
+        out.append(resample_protein(seeds, int(K), rng, f"SY{i:05d}.1"))
+    return out
+
+
+# ---- reads ---------------------------------------------------------------------------------
+
+def back_translate(consensus: str) -> np.ndarray:
+    return np.array([_NT[ch] for a in consensus for ch in CODON.get(a.upper(), "GCT")], dtype=np.uint8)
+
+
+def mutate(dom: np.ndarray, rng, sub: float, ins: float, dele: float) -> np.ndarray:
+    out = []
+    for b in dom:
+        u = rng.random()
+        if u < dele:
+            continue
+        if u < dele + ins:
+            out.append(rng.integers(0, 4))
+        out.append(rng.integers(0, 4) if rng.random() < sub else b)
+    return np.array(out, dtype=np.uint8)
+
+
+def synth_reads(nreads: int, length: int, consensus, seed: int, planted_every: int = 10, sub: float = 0.10,
+                ins: float = 0.03, dele: float = 0.03, first: int = 0):
+    """iid-uniform ACGT reads (read i depends on (seed, first + i) only); every `planted_every`-th carries
+    one planted domain: a profile consensus (at most 400 aa of it) back-translated, with substitutions,
+    insertions and deletions (10 % / 3 % / 3 %)."""
+    reads = []
+    for j in range(nreads):
+        i = first + j
+        rng = np.random.default_rng([seed, 7, i])
+        r = rng.integers(0, 4, size=length).astype(np.uint8)
+        if planted_every and i % planted_every == 0 and consensus:
+            cons = consensus[(i // planted_every) % len(consensus)]
+            if len(cons) > 400:
+                a = int(rng.integers(0, len(cons) - 400))
+                cons = cons[a : a + 400]
+            dom = mutate(back_translate(cons), rng, sub, ins, dele)[: max(1, length - 10)]
+            at = int(rng.integers(0, length - len(dom) + 1))
+            r[at : at + len(dom)] = dom
+        reads.append(r)
+    return reads
+
+
+# ---- .dcp writer ---------------------------------------------------------------------------
+
+def _u(n: int) -> bytes:  # MessagePack unsigned int
+    if n < 128:
+        return bytes([n])
+    if n < 1 << 8:
+        return b"\xcc" + struct.pack(">B", n)
+    if n < 1 << 16:
+        return b"\xcd" + struct.pack(">H", n)
+    if n < 1 << 32:
+        return b"\xce" + struct.pack(">I", n)
+    return b"\xcf" + struct.pack(">Q", n)
+
+
+def _s(text: str) -> bytes:
+    b = text.encode()
+    if len(b) < 32:
+        return bytes([0xA0 | len(b)]) + b
+    if len(b) < 1 << 8:
+        return b"\xd9" + struct.pack(">B", len(b)) + b
+    if len(b) < 1 << 16:
+        return b"\xda" + struct.pack(">H", len(b)) + b
+    return b"\xdb" + struct.pack(">I", len(b)) + b
+
+
+def _map(n: int) -> bytes:
+    return bytes([0x80 | n]) if n < 16 else (b"\xde" + struct.pack(">H", n) if n < 1 << 16 else b"\xdf" + struct.pack(">I", n))
+
+
+def _arr(n: int) -> bytes:
+    return bytes([0x90 | n]) if n < 16 else (b"\xdc" + struct.pack(">H", n) if n < 1 << 16 else b"\xdd" + struct.pack(">I", n))
+
+
+def _bin(b: bytes) -> bytes:
+    if len(b) < 1 << 8:
+        return b"\xc4" + struct.pack(">B", len(b)) + b
+    if len(b) < 1 << 16:
+        return b"\xc5" + struct.pack(">H", len(b)) + b
+    return b"\xc6" + struct.pack(">I", len(b)) + b
+
+
+def _ext(code: int, b: bytes) -> bytes:
+    fix = {1: 0xD4, 2: 0xD5, 4: 0xD6, 8: 0xD7, 16: 0xD8}
+    if len(b) in fix:
+        return bytes([fix[len(b)], code]) + b
+    if len(b) < 1 << 8:
+        return b"\xc7" + struct.pack(">B", len(b)) + bytes([code]) + b
+    if len(b) < 1 << 16:
+        return b"\xc8" + struct.pack(">H", len(b)) + bytes([code]) + b
+    return b"\xc9" + struct.pack(">I", len(b)) + bytes([code]) + b
+
+
+def _f32(a, legacy: bool) -> bytes:
+    if legacy:
+        return _ext(8, np.ascontiguousarray(a, ">f4").tobytes())
+    return _bin(np.ascontiguousarray(a, "<f4").tobytes())
+
+
+def pack_protein(p: dict, legacy: bool = False) -> bytes:
+    """protein_pack, c-core/protein.c:234-281."""
+    K = int(p["core_size"])
+    nuclt = _arr(2) + _f32(np.zeros(4, np.float32), legacy) + _f32(np.zeros(125, np.float32), legacy)
+    kn, kt, ke = _s("nuclt_dist"), _s("trans"), _s("emission")
+    nodes = b"".join(kn + nuclt + kt + _f32(p["trans"][i], legacy) + ke + _f32(p["emission"][i], legacy)
+                     for i in range(K + 1))
+    return (_map(10) + _s("accession") + _s(p["accession"]) + _s("gencode") + _u(int(p.get("gencode", 1)))
+            + _s("consensus") + _s(p["consensus"]) + _s("core_size") + _u(K) + _s("null_nuclt_dist") + nuclt
+            + _s("null_emission") + _f32(p["null_emission"], legacy) + _s("bg_nuclt_dist") + nuclt
+            + _s("bg_emission") + _f32(p["bg_emission"], legacy) + _s("nodes") + _map((K + 1) * 3) + nodes
+            + _s("BMk") + _f32(p["BMk"], legacy))
+
+
+def write_dcp(path: str, proteins, epsilon: float = 0.01, legacy: bool = False, rna: bool = False) -> None:
+    """proteins: dicts in the layout of deciphon_amd.host.Database.protein (an iterable: each is packed
+    and dropped, so a database larger than memory can be streamed from a generator via a temp list of
+    blobs on disk -- here the blobs are simply kept, the tests stay far below that)."""
+    blobs = [pack_protein(p, legacy) for p in proteins]
+    abc = (_map(4) + _s("symbols") + _s("ACGU" if rna else "ACGT") + _s("idx") + _ext(1, b"\0" * 94)
+           + _s("any_symbol_id") + _u(55) + _s("typeid") + _u(5 if rna else 4))
+    amino = (_map(4) + _s("symbols") + _s(AMINO) + _s("idx") + _ext(1, b"\0" * 94) + _s("any_symbol_id") + _u(55)
+             + _s("typeid") + _u(2))
+    sizes = [len(b) for b in blobs]
+    if legacy:
+        psz = _ext(6, np.array(sizes, ">u4").tobytes())
+    else:
+        psz = _arr(len(sizes)) + b"".join(_u(n) for n in sizes)
+    header = (_map(8) + _s("magic_number") + _u(0xC6F1) + _s("version") + _u(1) + _s("entry_dist") + _u(2)
+              + _s("epsilon") + b"\xca" + struct.pack(">f", float(epsilon)) + _s("abc") + abc + _s("amino") + amino
+              + _s("has_ga") + b"\xc3" + _s("protein_sizes") + psz)
+    with open(path, "wb") as f:
+        f.write(_map(2) + _s("header") + header + _s("proteins") + _arr(len(blobs)))
+        for b in blobs:
+            f.write(b)

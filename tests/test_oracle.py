@@ -110,6 +110,41 @@ def test_synthetic_tie_goldens(orc):
         assert zlib.crc32(nd.tobytes()) == int(g["nodes_crc"][it]), (it, K, L)
 
 
+def test_long_profile_goldens(orc):
+    """tests/large_cases.py: K = 257 .. 16383 (every multi-wave kernel class and the strip class at their
+    boundary sizes), windows up to 10 kb, continuous and tie-rich tables.  The expected bits were produced
+    by the reference's own viterbi.c (oracle/_ref via make_golden.py); the restatement must reproduce
+    scores, every trellis word (CRC32 of the whole trellis) and the unzipped path.  The path itself is
+    re-priced step by step (transitions and emissions it names, in double): it must be a legal path of the
+    model whose total is the Viterbi score -- a check of trellis_unzip's output (state ids, emission
+    sizes, N/J/C/I/D steps included) that does not go through any back-pointer."""
+    from large_cases import build_case, large_cases, path_cost
+
+    g = np.load(os.path.join(GOLDEN, "large_classes.npz"))
+    cases = large_cases()
+    assert len(cases) == len(g["K"])
+    kinds = set()
+    for c in cases:
+        i = c["idx"]
+        assert (c["K"], c["L"]) == (int(g["K"][i]), int(g["L"][i]))
+        prof, seq, xt = build_case(c, orc)
+        assert bits(orc.null(prof, xt, seq)) == int(g["null_bits"][i]), i
+        alt, xn, nd = orc.path(prof, xt, seq)  # the same DP as orc.cost, pointers kept
+        assert bits(alt) == int(g["alt_bits"][i]), (i, c)
+        assert zlib.crc32(xn.tobytes()) == int(g["xnodes_crc"][i]), (i, c)
+        assert zlib.crc32(nd.tobytes()) == int(g["nodes_crc"][i]), (i, c)
+        a, b = int(g["path_off"][i]), int(g["path_off"][i + 1])
+        if not np.isfinite(alt):
+            assert a == b
+            continue
+        ids, sizes = orc.unzip(prof.K, len(seq), xn, nd)
+        assert np.array_equal(ids, g["path_ids"][a:b]) and np.array_equal(sizes, g["path_sizes"][a:b]), i
+        total = path_cost(orc, prof, xt, seq, ids, sizes)
+        assert abs(total - float(alt)) <= 1e-4 * max(abs(float(alt)), 1.0), (i, total, float(alt))
+        kinds |= {int(s) >> 14 if int(s) >> 14 < 3 else int(s) & 0x3FFF for s in ids}
+    assert kinds >= {0, 1, 2, 3, 4, 5, 6, 7, 8, 9}  # M, I, D and S, N, B, E, J, C, T all occur on the paths
+
+
 def test_products_tsv_golden(orc, minifam, reads):
     """The reference's committed scan result (control/tests/files/snap.dcs): windows, hit
     spans, lrt as printed, and the (subsequence, state) pairs of the match column."""
@@ -143,8 +178,10 @@ def test_live_against_reference_viterbi(orc):
     if ref is None:
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     rng = np.random.default_rng(4242)
-    for it in range(300):
-        K = int(rng.choice([2, 3, 5, 8, 9, 17, 33, 64, 100, 173]))
+    for it in range(330):
+        # the last cases: sizes of every multi-wave kernel class and of the strip class
+        K = int(rng.choice([2, 3, 5, 8, 9, 17, 33, 64, 100, 173])) if it < 300 else \
+            int(rng.choice([257, 385, 600, 1000, 1537, 2049, 3000, 4097, 6000, 9000]))
         quant = [None, 1.0, 4.0][it % 3]
         prof = synth_profile(rng, K, quant, [0.0, 0.2][it % 2])
         seq = random_seq(rng, int(rng.integers(1, 80)))
