@@ -156,6 +156,7 @@ struct dcp_hip
   size_t committed = 0; // profiles whose descriptors are published
   DevBuf<float> d_pool;
   size_t pool_used = 0; // floats of d_pool holding profiles
+  int load_chunks = 0;  // staging chunks the last dcp_hip_load_dcp went through
   DevBuf<DcpProfileDev> d_profiles;
 
   // sequences
@@ -574,7 +575,16 @@ int dcp_hip_load_dcp(struct dcp_hip *x, char const *path, int first, int count)
   }
   if ((rc = ensure_pool(x, x->pool_used + off[(size_t)n]))) return rc;
 
-  size_t const chunk_floats = std::max<size_t>((size_t)64 << 20, profile_floats(DCP_MAX_CORE_SIZE)); // 256 MiB
+  // staging chunks of 256 MiB; DECIPHON_HIP_STAGE_MB shrinks them (never below one profile of the largest
+  // size present), which is how the tests drive a small database through many chunks
+  size_t chunk_floats = std::max<size_t>((size_t)64 << 20, profile_floats(DCP_MAX_CORE_SIZE));
+  if (char const *e = getenv("DECIPHON_HIP_STAGE_MB"))
+  {
+    size_t largest = 0;
+    for (int i = 0; i < n; ++i) largest = std::max(largest, off[(size_t)i + 1] - off[(size_t)i]);
+    chunk_floats = std::max<size_t>(((size_t)std::max(atol(e), 1L) << 20) / sizeof(float), largest);
+  }
+  int chunks = 0;
   float *stage[2] = {nullptr, nullptr};
   hipEvent_t done[2] = {nullptr, nullptr};
   bool busy[2] = {false, false};
@@ -654,8 +664,10 @@ int dcp_hip_load_dcp(struct dcp_hip *x, char const *path, int first, int count)
     busy[b] = true;
     b ^= 1;
     i0 = i1;
+    ++chunks;
   }
   cleanup();
+  x->load_chunks = chunks;
   for (int i = 0; i < n; ++i)
   {
     hps[(size_t)i].pool_off = (int64_t)(x->pool_used + off[(size_t)i]);
@@ -666,6 +678,8 @@ int dcp_hip_load_dcp(struct dcp_hip *x, char const *path, int first, int count)
 }
 
 int dcp_hip_num_profiles(struct dcp_hip const *x) { return x ? (int)x->profiles.size() : 0; }
+
+int dcp_hip_load_chunks(struct dcp_hip const *x) { return x ? x->load_chunks : 0; }
 
 int dcp_hip_profile_core_size(struct dcp_hip const *x, int i)
 {

@@ -5,6 +5,8 @@
 #include "host_logic.h"
 
 #include <string.h>
+#include <string>
+#include <vector>
 
 struct dcp_db
 {
@@ -43,10 +45,45 @@ int64_t dcp_db_protein_offset(struct dcp_db const *x, int i)
 int dcp_db_protein_core_size(struct dcp_db const *x, int i, int *core_size)
 {
   if (!x || !core_size) return DCP_EFUNCUSE;
-  DcpProtein p;
-  int rc = x->reader.read_protein(i, p);
-  if (rc) return rc;
-  *core_size = p.core_size;
+  std::string acc;
+  return x->reader.read_protein_head(i, *core_size, acc);
+}
+
+int dcp_db_core_sizes(struct dcp_db const *x, int32_t *core_sizes)
+{
+  if (!x || !core_sizes) return DCP_EFUNCUSE;
+  std::string acc;
+  for (int i = 0; i < x->reader.num_proteins(); ++i)
+  {
+    int K = 0;
+    int rc = x->reader.read_protein_head(i, K, acc);
+    if (rc) return rc;
+    core_sizes[i] = K;
+  }
+  return 0;
+}
+
+int dcp_db_partition_bounds(struct dcp_db const *x, int nparts, int balanced, int32_t *first)
+{
+  if (!x || !first) return DCP_EFUNCUSE;
+  if (nparts < 1) return DCP_EZEROPART;
+  int const n = x->reader.num_proteins();
+  std::vector<int32_t> K;
+  if (balanced)
+  {
+    K.resize((size_t)n);
+    int rc = dcp_db_core_sizes(x, K.data());
+    if (rc) return rc;
+  }
+  dcp_partition_bounds(n, balanced ? K.data() : nullptr, nparts, balanced != 0, first);
+  return 0;
+}
+
+int dcp_partition_bounds_of(int n, int32_t const *core_sizes, int nparts, int balanced, int32_t *first)
+{
+  if (n < 0 || !first || (balanced && n > 0 && !core_sizes)) return DCP_EFUNCUSE;
+  if (nparts < 1) return DCP_EZEROPART;
+  dcp_partition_bounds(n, core_sizes, nparts, balanced != 0, first);
   return 0;
 }
 

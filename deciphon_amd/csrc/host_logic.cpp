@@ -329,3 +329,28 @@ char const *dcp_error_string(int code)
   snprintf(unknown, sizeof unknown, "unknown error #%d", code);
   return unknown;
 }
+
+void dcp_partition_bounds(int n, int32_t const *core_sizes, int nparts, bool balanced, int32_t *first)
+{
+  first[0] = 0;
+  if (!balanced || !core_sizes)
+  {
+    for (int p = 0; p < nparts; ++p)
+    {
+      int const left = n - p > 0 ? n - p : 0;
+      first[p + 1] = first[p] + (left + nparts - 1) / nparts; // ceil((n - p) / nparts), c-core/partition_size.c:13-16
+    }
+    return;
+  }
+  std::vector<double> cum((size_t)n + 1, 0.0);
+  for (int i = 0; i < n; ++i) cum[(size_t)i + 1] = cum[(size_t)i] + (double)core_sizes[i];
+  int j = 0;
+  for (int p = 1; p < nparts; ++p)
+  {
+    double const target = cum[(size_t)n] * (double)p / (double)nparts;
+    while (j < n && cum[(size_t)j + 1] <= target) ++j;                                  // cum[j] <= target < cum[j + 1]
+    if (j < n && target - cum[(size_t)j] > cum[(size_t)j + 1] - target) ++j; // the nearer of the two
+    first[p] = j;
+  }
+  first[nparts] = n;
+}

@@ -50,3 +50,11 @@ struct DcpWindow
 
 // c-core/lrt.h:6-9
 inline float dcp_lrt(float null_loglik, float alt_loglik) { return -2 * (null_loglik - alt_loglik); }
+
+// Contiguous partitions of n profiles for nparts workers: first[p] .. first[p + 1] is partition p.
+// balanced = false: the reference's rule, ceil((n - p) / nparts) profiles each (c-core/partition_size.c:13-16
+// as c-core/protein_reader.c:112-128 applies it).  balanced = true: still contiguous and in order (the row
+// order of products.tsv depends on that, c-core/product.c:63-81), but the boundaries sit where the running
+// sum of core sizes comes closest to p/nparts of the total -- DP cells are proportional to K, not to the
+// number of profiles.
+void dcp_partition_bounds(int n, int32_t const *core_sizes, int nparts, bool balanced, int32_t *first);

@@ -149,7 +149,7 @@ std::string format_row(dcp_batch::Seq const &seq, int window, int wstart, int ws
   return out;
 }
 
-int setup_common(dcp_scan *x, char const *dbfile, int device, int index, int nparts, bool multi_hits,
+int setup_common(dcp_scan *x, char const *dbfile, int device, int index, int nparts, bool balanced, bool multi_hits,
                  bool hmmer3_compat, void (*callback)(void *), void *userdata)
 {
   if (!x || !dbfile) return raise(DCP_EFUNCUSE, __func__);
@@ -170,10 +170,23 @@ int setup_common(dcp_scan *x, char const *dbfile, int device, int index, int npa
   }
   else
   {
-    int first = 0;
-    for (int i = 0; i < index; ++i) first += (int)dcp_partition_size(N, nparts, i);
-    x->index_offset = first;
-    x->num_proteins = (int)dcp_partition_size(N, nparts, index);
+    // contiguous partitions, in database order: by count as the reference does (c-core/partition_size.c:13-16,
+    // c-core/protein_reader.c:112-128), or -- balanced -- by the running sum of core sizes
+    std::vector<int32_t> K, first((size_t)nparts + 1);
+    if (balanced)
+    {
+      K.resize((size_t)N);
+      std::string acc;
+      for (int i = 0; i < N; ++i)
+      {
+        int k = 0;
+        if ((rc = db.read_protein_head(i, k, acc))) return raise(rc, __func__, dbfile);
+        K[(size_t)i] = k;
+      }
+    }
+    dcp_partition_bounds(N, balanced ? K.data() : nullptr, nparts, balanced, first.data());
+    x->index_offset = first[(size_t)index];
+    x->num_proteins = first[(size_t)index + 1] - first[(size_t)index];
   }
   if (x->eng) dcp_hip_del(x->eng);
   x->eng = dcp_hip_new(device);
@@ -224,13 +237,27 @@ int dcp_scan_setup(struct dcp_scan *x, char const *dbfile, int port, int num_thr
   if (num_threads > 128) return raise(DCP_EMANYTHREADS, __func__); // THREAD_MAX, c-core/thread.h:7
   int device = 0;
   if (char const *d = getenv("DECIPHON_HIP_DEVICE")) device = atoi(d);
-  return setup_common(x, dbfile, device, 0, 1, multi_hits, hmmer3_compat, callback, userdata);
+  return setup_common(x, dbfile, device, 0, 1, false, multi_hits, hmmer3_compat, callback, userdata);
 }
 
 int dcp_scan_setup_partition(struct dcp_scan *x, char const *dbfile, int device, int index, int nparts,
                              bool multi_hits, bool hmmer3_compat, void (*callback)(void *), void *userdata)
 {
-  return setup_common(x, dbfile, device, index, nparts, multi_hits, hmmer3_compat, callback, userdata);
+  return setup_common(x, dbfile, device, index, nparts, false, multi_hits, hmmer3_compat, callback, userdata);
+}
+
+int dcp_scan_setup_partition_balanced(struct dcp_scan *x, char const *dbfile, int device, int index, int nparts,
+                                      bool multi_hits, bool hmmer3_compat, void (*callback)(void *), void *userdata)
+{
+  return setup_common(x, dbfile, device, index, nparts, true, multi_hits, hmmer3_compat, callback, userdata);
+}
+
+int dcp_scan_partition_range(struct dcp_scan const *x, int *first, int *count)
+{
+  if (!x || !first || !count) return DCP_EFUNCUSE;
+  *first = x->index_offset;
+  *count = x->num_proteins;
+  return 0;
 }
 
 int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *product_dir)

@@ -78,12 +78,14 @@ PRODUCTS_HEADER = "sequence\twindow\twindow_start\twindow_stop\thit\thit_start\t
 
 
 def scan_partitioned(dbfile, sequences, product_dir, multi_hits: bool = True, hmmer3_compat: bool = False,
-                     backend: str | None = None):
+                     backend: str | None = None, balanced: bool = True):
     """One scan over all GPUs of the job (run under torchrun, one process per GPU): rank i scans the
     i-th contiguous profile partition (c-core/partition_size.c:13-16 -- what thread i of
     c-core/scan.c:188-208 would take) against all the reads; the product rows are gathered in
     rank order, which is the reference's row order (c-core/product.c:63-81), and rank 0 writes
     product_dir/products.tsv.  sequences: [(id, name, text)].  Returns all rows on every rank.
+    balanced (default): the partition boundaries balance the sum of core sizes -- DP cells go with K -- instead
+    of the number of profiles; contiguous and in order either way, so the row order is the same.
 
     backend: "nccl" (RCCL; the default when every rank has its own GPU) or "gloo" (also lets several
     ranks share one GPU, as the tests on a one-GPU box do)."""
@@ -106,7 +108,7 @@ def scan_partitioned(dbfile, sequences, product_dir, multi_hits: bool = True, hm
     for sid, name, text in sequences:
         batch.add(Sequence(sid, name, text))
     part_dir = os.path.join(str(product_dir), f"part{rank}")
-    with Scan(dbfile, 0, 1, multi_hits, hmmer3_compat, False, partition=(device, rank, world)) as scan:
+    with Scan(dbfile, 0, 1, multi_hits, hmmer3_compat, False, partition=(device, rank, world), balanced=balanced) as scan:
         scan.run(part_dir, batch)
         rows = scan.products()
     rows = gather_rows(rows, f"cuda:{device}" if backend == "nccl" and world > 1 else "cpu")

@@ -53,6 +53,7 @@ def load_library() -> C.CDLL:
     L.dcp_hip_add_protein.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.dcp_hip_load_dcp.argtypes = [vp, C.c_char_p, i32, i32]
     L.dcp_hip_num_profiles.argtypes = [vp]
+    L.dcp_hip_load_chunks.argtypes = [vp]
     L.dcp_hip_profile_core_size.argtypes = [vp, i32]
     L.dcp_hip_profile_accession.argtypes = [vp, i32]
     L.dcp_hip_profile_accession.restype = C.c_char_p
@@ -169,6 +170,11 @@ class Engine:
 
     def load_dcp(self, path: str, first: int = 0, count: int = -1) -> None:
         self._check(self.lib.dcp_hip_load_dcp(self.h, os.fsencode(path), first, count))
+
+    @property
+    def load_chunks(self) -> int:
+        """Staging chunks the last load_dcp went through."""
+        return self.lib.dcp_hip_load_chunks(self.h)
 
     @property
     def num_profiles(self) -> int:

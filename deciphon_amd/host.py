@@ -33,6 +33,9 @@ def _lib():
     L.dcp_db_protein_offset.restype = C.c_int64
     L.dcp_db_protein_core_size.argtypes = [vp, i32, C.POINTER(i32)]
     L.dcp_db_read_protein.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.c_char_p, C.c_char_p]
+    L.dcp_db_core_sizes.argtypes = [vp, vp]
+    L.dcp_db_partition_bounds.argtypes = [vp, i32, i32, vp]
+    L.dcp_partition_bounds_of.argtypes = [i32, vp, i32, i32, vp]
     L.dcp_partition_size.argtypes = [C.c_long, C.c_long, C.c_long]
     L.dcp_partition_size.restype = C.c_long
     L.dcp_window_setup.argtypes = [C.POINTER(_Window), i32, i32]
@@ -89,6 +92,20 @@ class Database:
     def offset(self, i: int) -> int:
         return int(self.lib.dcp_db_protein_offset(self.h, i))
 
+    def core_sizes(self) -> np.ndarray:
+        K = np.zeros(len(self), np.int32)
+        if rc := self.lib.dcp_db_core_sizes(self.h, K.ctypes.data_as(C.c_void_p)):
+            raise HipError(rc)
+        return K
+
+    def partition_bounds(self, nparts: int, balanced: bool = False) -> np.ndarray:
+        """first[nparts + 1]: partition p = proteins first[p] .. first[p+1]-1 (c-core/protein_reader.c:112-128,
+        or boundaries that balance the sum of core sizes)."""
+        first = np.zeros(nparts + 1, np.int32)
+        if rc := self.lib.dcp_db_partition_bounds(self.h, nparts, int(balanced), first.ctypes.data_as(C.c_void_p)):
+            raise HipError(rc)
+        return first
+
     def protein(self, i: int) -> dict:
         k = C.c_int(0)
         rc = self.lib.dcp_db_protein_core_size(self.h, i, C.byref(k))
@@ -108,6 +125,16 @@ class Database:
             raise HipError(rc)
         return dict(core_size=K, accession=acc.value.decode(), consensus=cons.value.decode(), trans=trans,
                     emission=emission, BMk=BMk, null_emission=null, bg_emission=bg)
+
+
+def partition_bounds(core_sizes, nparts: int, balanced: bool = False) -> np.ndarray:
+    """first[nparts + 1] for profiles of the given core sizes (see Database.partition_bounds)."""
+    K = np.ascontiguousarray(core_sizes, np.int32)
+    first = np.zeros(nparts + 1, np.int32)
+    if rc := _lib().dcp_partition_bounds_of(len(K), K.ctypes.data_as(C.c_void_p), nparts, int(balanced),
+                                            first.ctypes.data_as(C.c_void_p)):
+        raise HipError(rc)
+    return first
 
 
 def partition_size(nelems: int, nparts: int, idx: int) -> int:

@@ -25,6 +25,8 @@ def _lib():
     L.dcp_scan_del.restype = None
     L.dcp_scan_setup.argtypes = [vp, C.c_char_p, i32, i32, C.c_bool, C.c_bool, C.c_bool, _CALLBACK, vp]
     L.dcp_scan_setup_partition.argtypes = [vp, C.c_char_p, i32, i32, i32, C.c_bool, C.c_bool, _CALLBACK, vp]
+    L.dcp_scan_setup_partition_balanced.argtypes = L.dcp_scan_setup_partition.argtypes
+    L.dcp_scan_partition_range.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.dcp_scan_run.argtypes = [vp, vp, C.c_char_p]
     L.dcp_scan_interrupt.argtypes = [vp]
     L.dcp_scan_interrupt.restype = None
@@ -76,10 +78,12 @@ class Batch:
 
 class Scan:
     """Same constructor and methods as python-core's Scan.  `partition=(device, index, nparts)`
-    (not in the reference) makes this scan own one contiguous profile partition on one GPU."""
+    (not in the reference) makes this scan own one contiguous profile partition on one GPU;
+    `balanced=True` puts the partition boundaries where they balance the sum of core sizes."""
 
     def __init__(self, dbfile, port: int = 0, num_threads: int = 1, multi_hits: bool = True,
-                 hmmer3_compat: bool = False, cache: bool = False, partition=None, on_window=None):
+                 hmmer3_compat: bool = False, cache: bool = False, partition=None, on_window=None,
+                 balanced: bool = False):
         self._lib = _lib()
         self._cscan = self._lib.dcp_scan_new()
         if not self._cscan:
@@ -102,8 +106,8 @@ class Scan:
                                           self._cb, None)
         else:
             device, index, nparts = partition
-            rc = self._lib.dcp_scan_setup_partition(self._cscan, path, device, index, nparts, multi_hits,
-                                                    hmmer3_compat, self._cb, None)
+            setup = self._lib.dcp_scan_setup_partition_balanced if balanced else self._lib.dcp_scan_setup_partition
+            rc = setup(self._cscan, path, device, index, nparts, multi_hits, hmmer3_compat, self._cb, None)
         if rc:
             self.free()
             raise DeciphonError(rc)
@@ -113,6 +117,13 @@ class Scan:
         basedir = getattr(snap, "basedir", snap)
         if rc := self._lib.dcp_scan_run(self._cscan, batch.cdata, str(basedir).encode()):
             raise DeciphonError(rc)
+
+    def partition_range(self):
+        """(first profile, number of profiles) of the database this scan owns."""
+        first, count = C.c_int(0), C.c_int(0)
+        if rc := self._lib.dcp_scan_partition_range(self._cscan, C.byref(first), C.byref(count)):
+            raise DeciphonError(rc)
+        return first.value, count.value
 
     def products(self):
         n = self._lib.dcp_scan_num_products(self._cscan)

@@ -147,6 +147,12 @@ enum
  * dcp_scan_setup.  Its products.tsv rows are that partition's, in database order. */
 int dcp_scan_setup_partition(struct dcp_scan *, char const *dbfile, int device, int index, int nparts,
                              bool multi_hits, bool hmmer3_compat, void (*callback)(void *), void *userdata);
+/* The same with partition boundaries that balance the sum of core sizes instead of the number of profiles
+ * (DP cells go with K): still contiguous and in database order, so the ranks' rows still
+ * concatenate to the whole scan's.  dcp_scan_partition_range reports what a scan owns. */
+int dcp_scan_setup_partition_balanced(struct dcp_scan *, char const *dbfile, int device, int index, int nparts,
+                                      bool multi_hits, bool hmmer3_compat, void (*callback)(void *), void *userdata);
+int dcp_scan_partition_range(struct dcp_scan const *, int *first, int *count);
 /* Number of product rows the last dcp_scan_run wrote, and row i (without newline). */
 long dcp_scan_num_products(struct dcp_scan const *);
 char const *dcp_scan_product(struct dcp_scan const *, long i);

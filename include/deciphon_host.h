@@ -33,6 +33,14 @@ int dcp_db_read_protein(struct dcp_db const *, int i, float *node_trans, float *
 
 /* partition_size (c-core/partition_size.c:13-16): proteins of partition idx out of nparts */
 long dcp_partition_size(long nelems, long nparts, long idx);
+/* core sizes of all proteins (read from the protein heads; nothing else of a protein is touched) */
+int dcp_db_core_sizes(struct dcp_db const *, int32_t *core_sizes);
+/* first[nparts + 1]: partition p holds proteins first[p] .. first[p+1]-1.  balanced = 0: the rule above, as
+ * c-core/protein_reader.c:112-128 applies it.  balanced = 1: contiguous and in order all the same, boundaries
+ * where the running sum of core sizes is closest to p/nparts of the total (DP cells go with K). */
+int dcp_db_partition_bounds(struct dcp_db const *, int nparts, int balanced, int32_t *first);
+/* the same rule on a plain array of n core sizes (core_sizes may be NULL when balanced = 0) */
+int dcp_partition_bounds_of(int n, int32_t const *core_sizes, int nparts, int balanced, int32_t *first);
 
 /* ---- window iteration: window_setup / window_next / window_set_last_hit_position
  * (c-core/window.c:7-50) ---- */

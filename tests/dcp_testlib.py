@@ -147,3 +147,45 @@ def reflib():
 
 def bits(x) -> int:
     return int(np.float32(x).view(np.uint32))
+
+
+def oracle_scan(orc, proteins, reads, multi_hits, hmmer3_compat, threads: int = 1):
+    """thread_run + process_window (c-core/thread.c:49-207) on the CPU oracle, without HMMER: the rows of
+    products.tsv in the reference's order.  proteins: objects with the fields of oracle.dcp_reader.Protein;
+    reads: [(id, text)].  threads > 1 spreads the proteins over a thread pool (ctypes drops the GIL)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    encoded = [(sid, text, orc.encode(text)) for sid, text in reads]
+
+    def one(prot):
+        rows = []
+        prof = orc.setup_profile(prot)
+        for sid, text, x in encoded:
+            w = orc.lib.orc_window_setup(len(x), prof.K)
+            while orc.lib.orc_window_next(C.byref(w)):
+                seq = np.ascontiguousarray(x[w.start : w.stop])
+                xt = orc.xtrans(max(len(seq) // 3, 1), multi_hits, hmmer3_compat)
+                lrt = orc.lrt(-orc.null(prof, xt, seq), -orc.cost(prof, xt, seq))
+                if not np.isfinite(lrt) or lrt < 0:
+                    continue
+                _, xn, nd = orc.path(prof, xt, seq)
+                ids, sizes = orc.unzip(prof.K, len(seq), xn, nd)
+                hit, last = orc.hits(ids, sizes)
+                if hit is None:
+                    continue
+                w.last_hit_pos = last
+                pos, cells = hit[0], []
+                for st, sz in zip(ids[hit[2] : hit[3]], sizes[hit[2] : hit[3]]):
+                    cells.append(f"{text[w.start + pos : w.start + pos + sz]},{orc.state_name(st)},,")
+                    pos += sz
+                rows.append(f"{sid}\t{w.idx}\t{w.start}\t{w.stop}\t0\t{hit[0]}\t{hit[1]}\t{prot.accession}\tdna\t"
+                            f"{lrt:.1f}\tnan\t" + ";".join(cells))
+        return rows
+
+    if threads <= 1:
+        parts = [one(p) for p in proteins]
+    else:
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(one, proteins))
+    return [r for part in parts for r in part]

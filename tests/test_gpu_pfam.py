@@ -1,0 +1,129 @@
+"""GPU: a Pfam-shaped database against 10 kb reads through the outer API (BASELINE configs[3] in small).
+
+200 profiles with a Pfam-like length distribution (log-normal, median 140) made of minifam node runs
+(deciphon_amd.synth), a few of them beyond one wavefront and one beyond 4096 positions, written as a pressed
+.dcp in BOTH array encodings (the current writer's `bin` / int-array form, c-core/write.c:59-66,
+c-core/database_writer.c:76-93, and the legacy `ext` form of the reference's committed fixture), scanned
+against 10 kb reads that carry error-bearing domains of several profiles -- with 1, 2 and 3 contiguous
+partitions, by count (c-core/partition_size.c:13-16) and balanced by core size.  Every product row (window
+chain, hit span, lrt, every step of every path) must equal the oracle-driven restatement of thread_run
+(c-core/thread.c:49-207); the ingest goes through several double-buffered staging chunks."""
+import os
+
+import numpy as np
+import pytest
+
+from dcp_testlib import GOLDEN, bits, oracle_scan
+from test_gpu_scan import run_scan
+
+pytestmark = pytest.mark.gpu
+
+NPROF, DB_SEED = 200, 77
+LONG = {17: 1100, 60: 1800, 111: 2300, 150: 4200}  # beyond one wavefront; 4200: the strip class
+
+
+@pytest.fixture(scope="module")
+def pfam(tmp_path_factory):
+    from types import SimpleNamespace
+
+    from deciphon_amd import synth
+
+    d = tmp_path_factory.mktemp("pfam")
+    seeds = synth.load_seeds(os.path.join(GOLDEN, "minifam.dcp"))
+    Ks = synth.pfam_like_lengths(NPROF, DB_SEED)
+    for i, K in LONG.items():
+        Ks[i] = K
+    proteins = synth.pfam_like_database(seeds, NPROF, DB_SEED, lengths=Ks)
+    synth.write_dcp(str(d / "pfam_bin.dcp"), proteins, legacy=False)
+    synth.write_dcp(str(d / "pfam_ext.dcp"), proteins, legacy=True)
+    # two 10 kb reads, each with domains of five profiles (12 % errors), the long ones among them
+    rng = np.random.default_rng(5)
+    reads = []
+    for r, picks in enumerate(((3, 17, 60, 88, 150), (9, 42, 111, 130, 199))):
+        x = rng.integers(0, 4, size=10000).astype(np.uint8)
+        for j, pi in enumerate(picks):
+            cons = proteins[pi]["consensus"]
+            a = int(rng.integers(0, max(len(cons) - 250, 1)))
+            dom = synth.mutate(synth.back_translate(cons[a : a + 250]), rng, 0.08, 0.02, 0.02)
+            at = 300 + j * 1900
+            x[at : at + len(dom)] = dom
+        reads.append((r + 1, "".join("ACGT"[v] for v in x)))
+    prots = [SimpleNamespace(**p) for p in proteins]
+    return SimpleNamespace(dir=d, proteins=prots, reads=reads, Ks=Ks)
+
+
+@pytest.fixture(scope="module")
+def expected(pfam, orc):
+    rows = oracle_scan(orc, pfam.proteins, pfam.reads, True, False, threads=min(os.cpu_count() or 1, 16))
+    profiles_hit = {r.split("\t")[7] for r in rows}
+    assert len(rows) >= 10 and len(profiles_hit) >= 8
+    assert {pfam.proteins[i].accession for i in LONG} <= profiles_hit  # the long profiles are among the hits
+    return rows
+
+
+def test_ingest_in_chunks_and_both_encodings_give_the_same_tables(pfam, monkeypatch):
+    """dcp_hip_load_dcp through >= 3 staging chunks (double-buffer reuse) equals the one-chunk load, and the
+    legacy encoding equals the current one: cost-pass scores of every profile, bit for bit."""
+    import deciphon_amd
+
+    read = deciphon_amd.encode(pfam.reads[0][1])[:600]
+    out = {}
+    for name, path, mb in (("one", "pfam_bin.dcp", None), ("chunks", "pfam_bin.dcp", "64"), ("ext", "pfam_ext.dcp", "48")):
+        if mb:
+            monkeypatch.setenv("DECIPHON_HIP_STAGE_MB", mb)
+        else:
+            monkeypatch.delenv("DECIPHON_HIP_STAGE_MB", raising=False)
+        with deciphon_amd.Engine(0) as eng:
+            eng.load_dcp(str(pfam.dir / path))
+            eng.commit()
+            out[name + "_chunks"] = eng.load_chunks
+            assert eng.num_profiles == NPROF and [eng.core_size(i) for i in range(NPROF)] == list(pfam.Ks)
+            eng.set_sequences([read])
+            eng.set_mode(True, False)
+            out[name] = eng.cost([(p, 0, 0, len(read)) for p in range(NPROF)])
+    assert out["one_chunks"] == 1 or out["one_chunks"] == 2  # 256 MiB chunks: the whole pool in one or two
+    assert out["chunks_chunks"] >= 3 and out["ext_chunks"] >= 4
+    for k in ("chunks", "ext"):
+        assert np.array_equal(out[k][0].view(np.uint32), out["one"][0].view(np.uint32))
+        assert np.array_equal(out[k][1].view(np.uint32), out["one"][1].view(np.uint32))
+
+
+def test_whole_scan_equals_oracle_thread_run(pfam, expected, tmp_path, monkeypatch):
+    monkeypatch.setenv("DECIPHON_HIP_STAGE_MB", "64")
+    rows = run_scan(str(tmp_path / "w"), pfam.reads, dbfile=str(pfam.dir / "pfam_bin.dcp"))
+    assert rows == expected
+
+
+def test_legacy_encoding_scan_equals_oracle_thread_run(pfam, expected, tmp_path):
+    rows = run_scan(str(tmp_path / "w"), pfam.reads, dbfile=str(pfam.dir / "pfam_ext.dcp"))
+    assert rows == expected
+
+
+@pytest.mark.parametrize("nparts", [2, 3])
+@pytest.mark.parametrize("balanced", [False, True])
+def test_partitions_concatenate_to_the_whole_scan(pfam, expected, tmp_path, nparts, balanced):
+    """Contiguous partitions (by count as c-core/protein_reader.c:112-128, or balanced by core size) scanned
+    separately give, in partition order, the rows of the whole scan (c-core/product.c:63-81)."""
+    from deciphon_amd import host
+    from deciphon_amd.scan import Batch, Scan, Sequence
+
+    db = str(pfam.dir / "pfam_bin.dcp")
+    bounds = host.Database(db).partition_bounds(nparts, balanced)
+    rows, owned = [], []
+    for idx in range(nparts):
+        batch = Batch()
+        for sid, text in pfam.reads:
+            batch.add(Sequence(sid, f"seq{sid}", text))
+        with Scan(db, 0, 1, True, False, False, partition=(0, idx, nparts), balanced=balanced) as scan:
+            first, count = scan.partition_range()
+            assert (first, first + count) == (int(bounds[idx]), int(bounds[idx + 1]))
+            owned.append(int(pfam.Ks[first : first + count].sum()))
+            scan.run(str(tmp_path / f"p{idx}"), batch)
+            rows += scan.products()
+    assert rows == expected
+    if not balanced:
+        assert [int(bounds[i + 1] - bounds[i]) for i in range(nparts)] == [
+            host.partition_size(NPROF, nparts, i) for i in range(nparts)]
+    else:
+        # no boundary is further from its target than half the core size next to it
+        assert max(owned) - min(owned) <= 2 * max(pfam.Ks)

@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 
+import dcp_testlib
 from dcp_testlib import GOLDEN, read_fasta
 from oracle.dcp_reader import read_dcp
 
@@ -17,48 +18,16 @@ DCP = os.path.join(GOLDEN, "minifam.dcp")
 
 
 def oracle_scan(orc, db, reads, multi_hits, hmmer3_compat):
-    """thread_run + process_window (c-core/thread.c:49-207) on the CPU oracle, without HMMER."""
-    rows = []
-    for prot in db.proteins:
-        prof = orc.setup_profile(prot)
-        for sid, text in reads:
-            x = orc.encode(text)
-            state = {"last": None}
-
-            def hook(idx):
-                return state["last"]
-
-            w = orc.lib.orc_window_setup(len(x), prof.K)
-            import ctypes as C
-
-            while orc.lib.orc_window_next(C.byref(w)):
-                seq = np.ascontiguousarray(x[w.start : w.stop])
-                xt = orc.xtrans(max(len(seq) // 3, 1), multi_hits, hmmer3_compat)
-                lrt = orc.lrt(-orc.null(prof, xt, seq), -orc.cost(prof, xt, seq))
-                if not np.isfinite(lrt) or lrt < 0:
-                    continue
-                _, xn, nd = orc.path(prof, xt, seq)
-                ids, sizes = orc.unzip(prof.K, len(seq), xn, nd)
-                hit, last = orc.hits(ids, sizes)
-                if hit is None:
-                    continue
-                w.last_hit_pos = last
-                pos, cells = hit[0], []
-                for st, sz in zip(ids[hit[2] : hit[3]], sizes[hit[2] : hit[3]]):
-                    cells.append(f"{text[w.start + pos : w.start + pos + sz]},{orc.state_name(st)},,")
-                    pos += sz
-                rows.append(f"{sid}\t{w.idx}\t{w.start}\t{w.stop}\t0\t{hit[0]}\t{hit[1]}\t{prot.accession}\tdna\t"
-                            f"{lrt:.1f}\tnan\t" + ";".join(cells))
-    return rows
+    return dcp_testlib.oracle_scan(orc, db.proteins, reads, multi_hits, hmmer3_compat)
 
 
-def run_scan(tmp_path, reads, multi_hits=True, hmmer3_compat=False, **kw):
+def run_scan(tmp_path, reads, multi_hits=True, hmmer3_compat=False, dbfile=DCP, **kw):
     from deciphon_amd.scan import Batch, Scan, Sequence
 
     batch = Batch()
     for sid, text in reads:
         batch.add(Sequence(sid, f"seq{sid}", text))
-    with Scan(DCP, 0, 1, multi_hits, hmmer3_compat, False, **kw) as scan:
+    with Scan(dbfile, 0, 1, multi_hits, hmmer3_compat, False, **kw) as scan:
         scan.run(tmp_path, batch)
         assert scan.progress() == 100
         rows = scan.products()

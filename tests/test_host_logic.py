@@ -199,3 +199,57 @@ def test_host_reader_under_sanitizers(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "fuzz done" in r.stdout and "K=173 acc=PF00742.20 rc=0" in r.stdout
     assert "window 1 [7959,10000)" in r.stdout  # c-core/window.c on a 10 kb read, K = 173
+
+
+def test_both_dcp_encodings_read_identically(tmp_path):
+    """The golden database (legacy `ext` encoding) re-encoded by deciphon_amd.synth.write_dcp in the CURRENT
+    writer's form (f32 arrays as `bin`, protein_sizes as an int array: c-core/write.c:59-66,
+    c-core/database_writer.c:76-93; read by c-core/read.c:118-132, c-core/database_reader.c:103-130) and in
+    the legacy form again: the product's reader returns bit-identical proteins from all three files, and so
+    does the independent Python reader.  (No reference-held fixture exists in the current encoding: that
+    form is pinned to the reference's writer SOURCE only -- parity unpinned beyond it.)"""
+    from deciphon_amd import host, synth
+    from oracle.dcp_reader import read_dcp
+
+    seeds = synth.load_seeds(os.path.join(GOLDEN, "minifam.dcp"))
+    assert [s["core_size"] for s in seeds] == [173, 241, 162]
+    for legacy in (False, True):
+        path = str(tmp_path / f"re{int(legacy)}.dcp")
+        synth.write_dcp(path, seeds, legacy=legacy)
+        db, py = host.Database(path), read_dcp(path)
+        assert len(db) == 3 and list(db.core_sizes()) == [173, 241, 162]
+        for i, s in enumerate(seeds):
+            p = db.protein(i)
+            assert (p["accession"], p["consensus"]) == (s["accession"], s["consensus"])
+            for k in ("trans", "emission", "BMk", "null_emission", "bg_emission"):
+                assert np.array_equal(p[k].view(np.uint32), s[k].view(np.uint32)), (legacy, i, k)
+                assert np.array_equal(getattr(py.proteins[i], k).view(np.uint32).ravel(), s[k].view(np.uint32).ravel())
+        db.close()
+
+
+def test_partition_bounds_by_count_and_balanced():
+    """By count: the reference's rule (c-core/partition_size.c:13-16 summed as c-core/protein_reader.c:112-128
+    does).  Balanced: contiguous, in order, and on a Pfam-shaped database (2*10^4 lengths from the log-normal
+    of deciphon_amd.synth) no GPU of 2..8 gets more than 1.05 x the mean sum of core sizes."""
+    from dcp_testlib import oracle
+    from deciphon_amd import host, synth
+
+    orc = oracle()
+    for n in (0, 1, 3, 10, 20000):
+        for parts in (1, 2, 3, 8, 128):
+            f = host.partition_bounds(np.ones(n, np.int32), parts, False)
+            assert [int(f[i + 1] - f[i]) for i in range(parts)] == [orc.partition_size(n, parts, i) for i in range(parts)]
+    K = synth.pfam_like_lengths(20000, 3)
+    for parts in (2, 3, 4, 8):
+        f = host.partition_bounds(K, parts, True)
+        assert f[0] == 0 and f[-1] == len(K) and np.all(np.diff(f) >= 0)
+        sums = np.array([K[f[i] : f[i + 1]].sum() for i in range(parts)], np.float64)
+        assert sums.max() / sums.mean() <= 1.05
+    # a sorted database (longest profiles last) is where splitting by count goes wrong and by size does not
+    Ks = np.sort(K)
+    by_count = host.partition_bounds(Ks, 8, False)
+    by_size = host.partition_bounds(Ks, 8, True)
+    s0 = np.array([Ks[by_count[i] : by_count[i + 1]].sum() for i in range(8)], np.float64)
+    s1 = np.array([Ks[by_size[i] : by_size[i + 1]].sum() for i in range(8)], np.float64)
+    assert s0.max() / s0.mean() > 2.0 and s1.max() / s1.mean() <= 1.05
+    assert list(host.partition_bounds(np.array([5, 5, 5], np.int32), 5, True)) == [0, 1, 1, 2, 2, 3]
