@@ -48,37 +48,48 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
         for c, v in sorted(acc[k].items()):
             print(f"    {c:36s} total={v:18.1f} per_dispatch={v / n:16.1f}")
 
-# HBM traffic per bench step (all dispatches of the Viterbi kernels in one step), for bench.py.
-# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide
-# coalesced reads (MI355X_MICROARCH.md, HBM), so the read side is doubled as that guide prescribes.
+# Per bench step (= all dispatches of the cost kernels in one step), for bench.py's roofline object:
+# HBM traffic and wave-level instruction counts.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+# counts 128-B requests as 64 B for wide coalesced reads (MI355X_MICROARCH.md, HBM), so the read side is
+# doubled as that guide prescribes.  bench.py --profile launches nothing but warmup + timed steps, so the
+# number of steps behind the sums is warmup + steps of the JSON line in trace.log.
 import json
-import re
 
+line = None
+for ln in open(os.path.join(out, "trace.log")):
+    if ln.startswith("{") and '"metric"' in ln:
+        line = json.loads(ln)
+if line is None:
+    print("no bench line in trace.log")
+    sys.exit(0)
+steps = line["steps"] + line["warmup"]
 fetch = write = 0.0
-insts = defaultdict(float)  # SQ_INSTS_* / GRBM_GUI_ACTIVE summed over the Viterbi kernels' dispatches
-steps = None
+insts = defaultdict(float)  # SQ_INSTS_* / GRBM_GUI_ACTIVE summed over the cost kernels' dispatches
+per_kernel_valu = defaultdict(float)
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        per_kernel = defaultdict(set)
         for r in csv.DictReader(open(f)):
-            if "dcp_cost_kernel" not in r["Kernel_Name"] and "dcp_path_kernel" not in r["Kernel_Name"]:
+            if "dcp_cost_kernel" not in r["Kernel_Name"] and "dcp_strip_kernel" not in r["Kernel_Name"]:
                 continue
-            per_kernel[r["Kernel_Name"]].add(r["Dispatch_Id"])
             if r["Counter_Name"] == "FETCH_SIZE":
                 fetch += float(r["Counter_Value"])
             if r["Counter_Name"] == "WRITE_SIZE":
                 write += float(r["Counter_Value"])
             if r["Counter_Name"].startswith("SQ_INSTS_") or r["Counter_Name"] in ("GRBM_GUI_ACTIVE", "SQ_WAVES"):
                 insts[r["Counter_Name"]] += float(r["Counter_Value"])
-        if per_kernel:
-            steps = max(len(v) for v in per_kernel.values())
-if steps:
-    tag = os.path.basename(os.path.normpath(out))
-    rec = {"fetch_kib_raw_per_step": fetch / steps, "write_kib_per_step": write / steps,
-           "hbm_bytes_per_step": (2.0 * fetch + write) * 1024.0 / steps, "dispatches_per_kernel": steps,
-           "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); separate --pmc passes"}
-    for k, v in sorted(insts.items()):  # wave-level instruction counts per step (bench.py: issue roofline)
-        rec[k.lower() + "_per_step"] = v / steps
-    dst = os.path.join(out, tag + "_traffic.json")  # copy it to profiles/ to have bench.py report it
-    json.dump(rec, open(dst, "w"), indent=1)
-    print("== traffic ==", json.dumps(rec))
+            if r["Counter_Name"] == "SQ_INSTS_VALU":
+                per_kernel_valu[short(r["Kernel_Name"])] += float(r["Counter_Value"])
+tag = os.path.basename(os.path.normpath(out))
+rec = {"workload_key": line["config"].get("workload_key"), "kernel_source_hash": line["config"].get("kernel_source_hash"),
+       "workload": line["config"]["workload"], "steps_profiled": steps,
+       "cells_per_step": line["config"].get("cells_per_step_per_gpu"),
+       "fetch_kib_raw_per_step": fetch / steps, "write_kib_per_step": write / steps,
+       "hbm_bytes_per_step": (2.0 * fetch + write) * 1024.0 / steps,
+       "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); separate --pmc passes; sums over every "
+               "cost-kernel dispatch / (warmup + steps)"}
+for k, v in sorted(insts.items()):  # wave-level instruction counts per step (bench.py: issue roofline)
+    rec[k.lower() + "_per_step"] = v / steps
+rec["sq_insts_valu_per_step_by_kernel"] = {k: v / steps for k, v in sorted(per_kernel_valu.items())}
+dst = os.path.join(out, tag + "_traffic.json")  # copy it to profiles/ to have bench.py report it
+json.dump(rec, open(dst, "w"), indent=1)
+print("== traffic ==", json.dumps(rec))

@@ -16,7 +16,8 @@ from dcp_testlib import GOLDEN
 from oracle.dcp_reader import read_dcp
 
 db = read_dcp(os.path.join(GOLDEN, "minifam.dcp"))
-reads = bench.synth_reads(1000, 3000, [p.consensus for p in db.proteins])
+from deciphon_amd import synth
+reads = synth.synth_reads(1000, 3000, [p.consensus for p in db.proteins], bench.SEED)
 eng = deciphon_amd.Engine(0)
 eng.load_dcp(os.path.join(GOLDEN, "minifam.dcp"))
 eng.commit()

@@ -328,10 +328,11 @@ def test_full_size_config2_properties(engine, orc):
     workload): a random sample of windows against the oracle, bit-identical results across
     two runs and across the staged (bench) entry points, and the planted domains are found."""
     import bench
+    from deciphon_amd import synth
     from oracle.dcp_reader import read_dcp
 
     db = read_dcp(os.path.join(GOLDEN, "minifam.dcp"))
-    reads = bench.synth_reads(1000, 3000, [p.consensus for p in db.proteins])
+    reads = synth.synth_reads(1000, 3000, [p.consensus for p in db.proteins], bench.SEED)
     engine.clear_profiles()
     engine.load_dcp(os.path.join(GOLDEN, "minifam.dcp"))
     engine.commit()
@@ -357,7 +358,7 @@ def test_full_size_config2_properties(engine, orc):
         assert bits(nul[i]) == bits(orc.null(profs[p], xt, reads[s]))
         assert bits(alt[i]) == bits(orc.cost(profs[p], xt, reads[s]))
     lrt = -2.0 * ((-nul) - (-alt))
-    planted = [(s // 10 % 3, s) for s in range(0, 1000, 10)]  # bench.synth_reads: read s carries profile (s/10)%3
+    planted = [(s // 10 % 3, s) for s in range(0, 1000, 10)]  # synth_reads: read s carries profile (s/10)%3
     found = sum(lrt[p * 1000 + s] > 0 for p, s in planted)
     assert found >= 90, found
     others = np.ones(3000, bool)
