@@ -1,0 +1,234 @@
+// viterbi_pack.h -- viterbi_null + viterbi_cost of SEVERAL windows per wavefront.
+//
+// CostWave (viterbi_body.h) gives one window a whole wavefront: a profile of K positions uses
+// ceil(K / Q) of 64 lanes, and everything a DP row pays once per wavefront -- the chains of the
+// special states, the E reduction, B, the k-1 shifts, the control of the lazy D->D loop -- is paid
+// per window.  Here a wavefront is cut into G = 64 / S groups of S lanes and each group runs its
+// own window of the SAME profile: the per-row work is paid once per G windows and short profiles
+// fill the lanes (K = 3: 16 windows per wavefront instead of 3 busy lanes of 64).
+//
+//   lane = g * S + e.  e = 0 is the group's SEPARATOR: it owns no position, its transition and
+//   emission operands are the +inf padding of the tables, so its M, I, D stay +inf -- which is
+//   exactly what the k-1 neighbour of position 0 must be (shift() injects +inf there,
+//   c-core/intrinsics.h:95-106).  Every k-1 shift is then one plain DPP wave_shr:1 for any S.
+//   e = 1 .. S-1 own positions k = (e - 1) * Q + q: a group holds K <= (S - 1) * Q.
+//   The special states ride in lanes e = 0..3 of a separate register (N, J, C and the null
+//   model R), as in CostWave.
+//
+// The recurrences, their fp32 association and the folded rows (Mpre, Ipre) are CostWave's: see the
+// header of viterbi_body.h for why they give the reference's bits (c-core/viterbi.c:451-600,696-719).
+// What changes is only where uniform values live: codes, null/bg emissions, special transitions and
+// E, B are per GROUP, so they sit in VGPRs (loaded / reduced per lane) instead of SGPRs.  Windows of
+// one wavefront may differ in length: the row loop runs to the longest, and a group captures its
+// results at its own last row.
+#pragma once
+#include "dcp_types.h"
+
+#ifndef DCP_FN
+#error "include a lane_ops_*.h before viterbi_pack.h"
+#endif
+
+#ifndef DCP_INF
+#define DCP_INF (__builtin_inff())
+#endif
+#ifndef DCP_SL
+#define DCP_SL(P, t) (((P) + 5 - (t)) % 5)
+#endif
+
+// TURNS = lazy D->D turns taken unconditionally before the first vote (a turn is 2Q+2 instructions; a vote
+// costs a ballot, a scalar branch and the copies of a loop: on real profiles the first turns are almost
+// always needed, so they are cheaper straight-line)
+template <int Q, int S, int TURNS = 2> struct PackWave
+{
+  static_assert(S == 4 || S == 8 || S == 16 || S == 32, "groups of 4, 8, 16 or 32 lanes");
+  enum { G = 64 / S, CAP = (S - 1) * Q };
+  lu lane, e;           // lane in the wave, lane in its group
+  lf BM[Q], MM[Q], MI[Q], MD[Q], IM[Q], II[Q], DM[Q], DD[Q];
+  lf Mpre[5][Q], Ipre[5][Q], Spre[5];
+  lf em[5][Q], nil[5], bgv[5];
+  lu code[5];           // codes of the next row to fetch (per group)
+  lf sa, sb, nbjb;      // special transitions by special lane: Xpre = min(E + sa, X + sb); B candidates X + nbjb
+  lf X, E;
+  lf EBv, ETv, CTv;
+  lf shM, shI, shD;     // destinations of the k-1 shifts (lane 0 of the wave stays +inf)
+  lf Xs, Es;            // X and E of the group's own last row
+  lu Lg;                // window length of the lane's group (0: idle group)
+  lu crow;              // index of the group's code row 0
+  PackSrc src;
+
+  DCP_FN void fetch_codes(int l) { load_code_row(src, crow + (uint32_t)l, code); }
+
+  // emissions and null/bg of the row whose codes sit in `code`
+  DCP_FN void fetch_rows()
+  {
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+    {
+      load_pack_hdr(src, code[t], nil[t], bgv[t]);
+      load_pack_q<Q>(src, code[t], em[t]);
+    }
+  }
+
+  DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, DcpCodeRow const *__restrict__ code_rows,
+                   uint32_t ncode_rows, float const *__restrict__ xt_table, DcpPack const &pk)
+  {
+    lane = lane_ids();
+    e = lane & lu_splat((uint32_t)(S - 1));
+    lu const g = lane_shr(lane, S == 4 ? 2 : S == 8 ? 3 : S == 16 ? 4 : 5);
+    int const Kp = pf.Kp;
+    // column of the lane's first position; the separator reads the last Q columns of the padded row (+inf)
+    lu const col = lselu(lequ(e, lu_splat(0)), lu_splat((uint32_t)(Kp - Q)), (e - lu_splat(1)) * (uint32_t)Q);
+    src = packsrc_make(pool + pf.rows_off, Kp, code_rows, ncode_rows, col);
+    float const *__restrict__ trans = pool + pf.trans_off;
+    load_cols<Q>(trans + DCP_BM * Kp, col, BM);
+    load_cols<Q>(trans + DCP_MM * Kp, col, MM);
+    load_cols<Q>(trans + DCP_MI * Kp, col, MI);
+    load_cols<Q>(trans + DCP_MD * Kp, col, MD);
+    load_cols<Q>(trans + DCP_IM * Kp, col, IM);
+    load_cols<Q>(trans + DCP_II * Kp, col, II);
+    load_cols<Q>(trans + DCP_DM * Kp, col, DM);
+    load_cols<Q>(trans + DCP_DD * Kp, col, DD);
+    Lg = load_u32_at(reinterpret_cast<uint32_t const *>(pk.L), g);
+    crow = load_u32_at(pk.code_row, g);
+    lu const xrow = load_u32_at(reinterpret_cast<uint32_t const *>(pk.xt_row), g) * (uint32_t)DCP_XT_STRIDE;
+    lf const inf = lf_splat(DCP_INF);
+    lm const l0 = lequ(e, lu_splat(0)), l1 = lequ(e, lu_splat(1)), l2 = lequ(e, lu_splat(2)), l3 = lequ(e, lu_splat(3));
+    lf const NB = load_f32_at(xt_table, xrow + (uint32_t)DCP_NB), JB = load_f32_at(xt_table, xrow + (uint32_t)DCP_JB);
+    lf const RR = load_f32_at(xt_table, xrow + (uint32_t)DCP_RR), SN = load_f32_at(xt_table, xrow + (uint32_t)DCP_SN);
+    lf const SB = load_f32_at(xt_table, xrow + (uint32_t)DCP_SB);
+    EBv = load_f32_at(xt_table, xrow + (uint32_t)DCP_EB);
+    ETv = load_f32_at(xt_table, xrow + (uint32_t)DCP_ET);
+    CTv = load_f32_at(xt_table, xrow + (uint32_t)DCP_CT);
+    // e: 0 = N, 1 = J, 2 = C, 3 = R.  Xpre = min(E + sa, X + sb); B = min(E + EB, N + NB, J + JB)
+    sa = lsel(l1, load_f32_at(xt_table, xrow + (uint32_t)DCP_EJ), lsel(l2, load_f32_at(xt_table, xrow + (uint32_t)DCP_EC), inf));
+    sb = lsel(l0, load_f32_at(xt_table, xrow + (uint32_t)DCP_NN),
+              lsel(l1, load_f32_at(xt_table, xrow + (uint32_t)DCP_JJ),
+                   lsel(l2, load_f32_at(xt_table, xrow + (uint32_t)DCP_CC), lsel(l3, RR, inf))));
+    nbjb = lsel(l0, NB, lsel(l1, JB, inf));
+    shM = shI = shD = inf;
+    // row 0 (c-core/viterbi.c:471-473, :703): S = 0, B = SB, R = -RR, rest +inf
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+    {
+      Spre[s] = inf;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+      {
+        Mpre[s][q] = inf;
+        Ipre[s][q] = inf;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) Mpre[0][q] = SB + BM[q];
+    Spre[0] = lsel(l0, lf_splat(0.0f) + SN, lsel(l3, lneg(RR) + RR, inf));
+    X = lsel(l3, lneg(RR), inf);
+    E = inf;
+    Xs = X;
+    Es = inf;
+  }
+
+  template <int P> DCP_FN void row(int l, int Lmax)
+  {
+    lf M[Q], I[Q], D[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      M[q] = lmin3(lmin3(Mpre[DCP_SL(P, 5)][q] + em[4][q], Mpre[DCP_SL(P, 4)][q] + em[3][q],
+                         Mpre[DCP_SL(P, 3)][q] + em[2][q]),
+                   Mpre[DCP_SL(P, 2)][q] + em[1][q], Mpre[DCP_SL(P, 1)][q] + em[0][q]);
+      I[q] = lmin3(lmin3(Ipre[DCP_SL(P, 5)][q] + bgv[4], Ipre[DCP_SL(P, 4)][q] + bgv[3],
+                         Ipre[DCP_SL(P, 3)][q] + bgv[2]),
+                   Ipre[DCP_SL(P, 2)][q] + bgv[1], Ipre[DCP_SL(P, 1)][q] + bgv[0]);
+    }
+    X = lmin3(lmin3(Spre[DCP_SL(P, 5)] + nil[4], Spre[DCP_SL(P, 4)] + nil[3], Spre[DCP_SL(P, 3)] + nil[2]),
+              Spre[DCP_SL(P, 2)] + nil[1], Spre[DCP_SL(P, 1)] + nil[0]);
+
+    // this row's operands are consumed: the next row's (its codes arrived a row ago) go out now,
+    // together with the codes of the row after it
+    if (l < Lmax)
+    {
+      fetch_rows();
+      fetch_codes(l + 2);
+    }
+
+    lf m = M[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q) m = lmin(m, M[q]);
+    lf const Msh0 = lane_shift_up_keep(M[Q - 1], shM);
+    lf const Ish0 = lane_shift_up_keep(I[Q - 1], shI);
+    E = group_min<S>(m);                                   // E_l = min_k M_l[k] (see viterbi_body.h)
+    lf const B = lmin(E + EBv, group_min<S>(X + nbjb));    // c-core/viterbi.c:495-496,582-583
+
+    // D_l[k] = min(M_l[k-1] + MD[k], D_l[k-1] + DD[k]) (c-core/viterbi.c:538,553-580): serial inside a
+    // lane, then carried across lanes until no lane improves (the reference's lazy loop, :569-580)
+    D[0] = Msh0 + MD[0];
+#pragma unroll
+    for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
+    lf Dsh0 = lane_shift_up_keep(D[Q - 1], shD);
+    lf x = Dsh0 + DD[0];
+#pragma unroll
+    for (int turn = 0; turn < TURNS; ++turn)
+    {
+      D[0] = lmin(D[0], x);
+#pragma unroll
+      for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+      Dsh0 = lane_shift_up_keep(D[Q - 1], shD);
+      x = Dsh0 + DD[0];
+    }
+    while (wave_any(llt(x, D[0])))
+    {
+      D[0] = lmin(D[0], x);
+#pragma unroll
+      for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+      Dsh0 = lane_shift_up_keep(D[Q - 1], shD);
+      x = Dsh0 + DD[0];
+    }
+
+    // fold row l into the ring (slot P held row l-5, no longer needed)
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      lf const Ml = q ? M[q ? q - 1 : 0] : Msh0;
+      lf const Il = q ? I[q ? q - 1 : 0] : Ish0;
+      lf const Dl = q ? D[q ? q - 1 : 0] : Dsh0;
+      Mpre[P][q] = lmin3(B + BM[q], Ml + MM[q], lmin(Il + IM[q], Dl + DM[q]));
+      Ipre[P][q] = lmin(I[q] + II[q], M[q] + MI[q]);
+    }
+    Spre[P] = lmin(E + sa, X + sb);
+    // the group's own last row: keep what its results are made of
+    lm const last = lequ(Lg, lu_splat((uint32_t)l));
+    Xs = lsel(last, X, Xs);
+    Es = lsel(last, E, Es);
+  }
+
+  // out[2 * slot] = viterbi_null(), out[2 * slot + 1] = viterbi_cost() of every group's window
+  DCP_FN void run(int Lmax, float *__restrict__ out, DcpPack const &pk)
+  {
+    if (Lmax > 0)
+    {
+      fetch_codes(1);
+      fetch_rows();
+      fetch_codes(2);
+    }
+    int l = 1;
+    for (; l + 4 <= Lmax; l += 5)
+    {
+      row<1>(l, Lmax);
+      row<2>(l + 1, Lmax);
+      row<3>(l + 2, Lmax);
+      row<4>(l + 3, Lmax);
+      row<0>(l + 4, Lmax);
+    }
+    if (l <= Lmax) row<1>(l++, Lmax);
+    if (l <= Lmax) row<2>(l++, Lmax);
+    if (l <= Lmax) row<3>(l++, Lmax);
+    if (l <= Lmax) row<4>(l++, Lmax);
+    // lane e = 2 holds C, e = 3 holds R of the group's last row (c-core/viterbi.c:585-586,599,718)
+    lu const g = lane_shr(lane, S == 4 ? 2 : S == 8 ? 3 : S == 16 ? 4 : 5);
+    lu const slot = load_u32_at(reinterpret_cast<uint32_t const *>(pk.out), g);
+    lm const active = llt_u(lu_splat(0), Lg);
+    lf const T = lmin(Es + ETv, Xs + CTv);
+    store_f32_where(out, slot * 2u + 1u, land(active, lequ(e, lu_splat(2))), T);
+    store_f32_where(out, slot * 2u, land(active, lequ(e, lu_splat(3))), Xs);
+  }
+};
