@@ -54,3 +54,15 @@ struct DcpProblem
   int32_t out;      // slot in the output arrays
   int64_t trellis;  // path pass: offset (in bytes) of this problem's trellis in the arena
 };
+
+// Up to 16 windows of ONE profile that share a wavefront (viterbi_pack.h): group g of the wave runs window g.
+// L[g] = 0 marks an idle group.  code_row is an index into the DcpCodeRow array (the array stays below 2^32 rows).
+struct DcpPack
+{
+  int32_t profile;
+  int32_t Lmax;          // the longest window of the pack: the row loop runs to it
+  int32_t L[16];
+  int32_t xt_row[16];    // max(L / 3, 1), c-core/thread.c:112
+  int32_t out[16];       // slot in the output arrays
+  uint32_t code_row[16]; // index of the window's position 0 in the DcpCodeRow array
+};

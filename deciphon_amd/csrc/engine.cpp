@@ -125,6 +125,7 @@ struct TableArena
 struct HostProfile
 {
   int K, Kp, Q, W, cls;
+  int pack = -1; // shape of the packed cost kernel (several windows per wavefront), -1: none
   int64_t pool_off; // floats
   std::string accession;
 };
@@ -149,6 +150,8 @@ struct dcp_hip
   // classes (few problems each in small scans) share the GPU instead of queueing
   hipStream_t qstream[DCP_NUM_CLASSES] = {nullptr};
   hipEvent_t fork_ev = nullptr, join_ev[DCP_NUM_CLASSES] = {nullptr};
+  hipStream_t pstream[DCP_NUM_PACK_SHAPES] = {nullptr}; // the packed cost kernels, one stream per shape
+  hipEvent_t pjoin_ev[DCP_NUM_PACK_SHAPES] = {nullptr};
   std::string err;
 
   // profiles
@@ -174,6 +177,7 @@ struct dcp_hip
 
   // problems / results
   DevBuf<DcpProblem> d_problems;
+  DevBuf<DcpPack> d_packs;         // cost pass: windows of short profiles, several per wavefront
   DevBuf<float> d_out;
   DevBuf<int64_t> d_aux;           // strip class, literal path pass: table and scratch addresses per window
   DevBuf<float> d_ring;            // strip class (K > 4096): the rings of folded rows, one per workgroup in flight
@@ -191,6 +195,7 @@ struct dcp_hip
   std::vector<PathResult> paths;
   std::vector<DcpProblem> staged_problems; // dcp_hip_stage
   int staged_c_begin[DCP_NUM_CLASSES + 1] = {0};
+  int staged_pk_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
   double staged_cells = 0;
   int staged_n = -1;
 };
@@ -235,8 +240,10 @@ int ensure_xt(dcp_hip *x, int rows_needed)
 
 struct Staged
 {
-  std::vector<DcpProblem> problems;       // sorted by (class, profile)
+  std::vector<DcpProblem> problems;       // sorted by (class, profile); cost pass: without the packed ones
   int c_begin[DCP_NUM_CLASSES + 1] = {0}; // problems of class c are [c_begin[c], c_begin[c+1])
+  std::vector<DcpPack> packs;             // cost pass: sorted by (shape, profile)
+  int pk_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
   double cells = 0;
   size_t arena_bytes = 0;
 };
@@ -284,6 +291,52 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
     }
   }
   st.arena_bytes = arena;
+  // Cost pass: the windows of short profiles go several to a wavefront (viterbi_pack.h).  They leave the
+  // problem list and come back as packs: up to G windows of ONE profile each, longest first, so that the
+  // windows of a pack are of similar length (a pack runs as many rows as its longest window).
+  // DECIPHON_HIP_PACK=0 keeps every window on the one-window-per-wavefront kernels (tests compare the two).
+  st.packs.clear();
+  for (int s = 0; s <= DCP_NUM_PACK_SHAPES; ++s) st.pk_begin[s] = 0;
+  char const *pack_env = getenv("DECIPHON_HIP_PACK");
+  bool const packing = arena_kind == ARENA_NONE && !(pack_env && pack_env[0] == '0') &&
+                       (uint64_t)x->row_off.back() < ((uint64_t)1 << 32); // code rows are addressed by u32 index
+  if (packing)
+  {
+    std::vector<DcpProblem> packed, rest;
+    for (DcpProblem const &p : st.problems)
+      (x->profiles[(size_t)p.profile].pack >= 0 ? packed : rest).push_back(p);
+    std::stable_sort(packed.begin(), packed.end(), [&](DcpProblem const &a, DcpProblem const &b) {
+      int sa = x->profiles[(size_t)a.profile].pack, sb = x->profiles[(size_t)b.profile].pack;
+      if (sa != sb) return sa < sb;
+      if (a.profile != b.profile) return a.profile < b.profile;
+      return a.L > b.L;
+    });
+    int shape = 0;
+    for (size_t i = 0; i < packed.size();)
+    {
+      int const sh = x->profiles[(size_t)packed[i].profile].pack;
+      while (shape < sh) st.pk_begin[++shape] = (int)st.packs.size();
+      int pq = 0, ps = 0;
+      dcp_pack_shape(sh, &pq, &ps);
+      int const G = 64 / ps;
+      DcpPack pk;
+      memset(&pk, 0, sizeof pk);
+      pk.profile = packed[i].profile;
+      pk.Lmax = packed[i].L;
+      int g = 0;
+      for (; g < G && i < packed.size() && packed[i].profile == pk.profile; ++g, ++i)
+      {
+        pk.L[g] = packed[i].L;
+        pk.xt_row[g] = packed[i].xt_row;
+        pk.out[g] = packed[i].out;
+        pk.code_row[g] = (uint32_t)packed[i].code_row;
+      }
+      st.packs.push_back(pk);
+    }
+    while (shape < DCP_NUM_PACK_SHAPES) st.pk_begin[++shape] = (int)st.packs.size();
+    st.problems.swap(rest);
+  }
+  int const nu = (int)st.problems.size(); // windows that keep a wavefront (or a workgroup) to themselves
   std::stable_sort(st.problems.begin(), st.problems.end(), [&](DcpProblem const &a, DcpProblem const &b) {
     int ca = x->profiles[(size_t)a.profile].cls, cb = x->profiles[(size_t)b.profile].cls;
     if (ca != cb) return ca < cb;
@@ -293,20 +346,28 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
   for (int c = 0; c < DCP_NUM_CLASSES; ++c)
   {
     st.c_begin[c] = i;
-    while (i < n && x->profiles[(size_t)st.problems[(size_t)i].profile].cls == c) ++i;
+    while (i < nu && x->profiles[(size_t)st.problems[(size_t)i].profile].cls == c) ++i;
   }
   st.c_begin[DCP_NUM_CLASSES] = i;
-  if (i != n) return fail(x, DCP_ELARGECORESIZE, "profile outside every kernel class");
+  if (i != nu) return fail(x, DCP_ELARGECORESIZE, "profile outside every kernel class");
   if (st.c_begin[DCP_STRIP_CLASS + 1] > st.c_begin[DCP_STRIP_CLASS])
     HIP_TRY(x, x->d_ring.reserve((size_t)DCP_RING_SLOTS * DCP_RING_FLOATS), DCP_ENOMEM);
   int rc = ensure_xt(x, max_s + 1);
   if (rc) return rc;
   x->staged_n = -1; // the device problem list is about to be replaced
-  HIP_TRY(x, x->d_problems.reserve((size_t)std::max(n, 1)), DCP_ENOMEM);
-  if (n)
-    HIP_TRY(x, hipMemcpyAsync(x->d_problems.p, st.problems.data(), (size_t)n * sizeof(DcpProblem),
+  HIP_TRY(x, x->d_problems.reserve((size_t)std::max(nu, 1)), DCP_ENOMEM);
+  if (nu)
+    HIP_TRY(x, hipMemcpyAsync(x->d_problems.p, st.problems.data(), (size_t)nu * sizeof(DcpProblem),
                               hipMemcpyHostToDevice, x->stream),
             DCP_EFUNCUSE);
+  if (!st.packs.empty())
+  {
+    HIP_TRY(x, x->d_packs.reserve(st.packs.size()), DCP_ENOMEM);
+    HIP_TRY(x, hipMemcpyAsync(x->d_packs.p, st.packs.data(), st.packs.size() * sizeof(DcpPack), hipMemcpyHostToDevice,
+                              x->stream),
+            DCP_EFUNCUSE);
+    // st.packs is read by the copy until the stream gets there; the callers keep `st` alive across their sync
+  }
   return 0;
 }
 
@@ -354,31 +415,69 @@ int launch_all(dcp_hip *x, Staged const &st, bool path)
   return 0;
 }
 
-// Cost pass.  A small launch that mixes single-wave classes goes out as ONE fused
-// kernel (classes 0..3 are contiguous in the sorted problem list); large launches keep
-// one kernel per class, which fills the GPU by itself and has its own register budget.
+// Cost pass.  The packed kernels (short profiles, several windows per wavefront) go out first, one stream per
+// shape.  Of the rest, a small launch that mixes single-wave classes goes out as ONE fused kernel (classes 0..3
+// are contiguous in the sorted problem list); large launches keep one kernel per class, which fills the GPU
+// by itself and has its own register budget.  Everything is forked from and joined back into x->stream.
 int launch_cost_all(dcp_hip *x, Staged const &st)
 {
   int const single_wave = st.c_begin[4] - st.c_begin[0];
   int mixed = 0;
   for (int c = 0; c < 4; ++c) mixed += st.c_begin[c + 1] > st.c_begin[c];
-  if (mixed < 2 || single_wave > 16384) return launch_all(x, st, false);
-  // the other classes of a small launch run beside the fused kernel, on their own streams
-  bool fork = false;
-  for (int c = 4; c < DCP_NUM_CLASSES; ++c) fork = fork || st.c_begin[c + 1] > st.c_begin[c];
+  bool const fused = mixed >= 2 && single_wave <= 16384;
+  int kernels = fused ? 1 : 0;
+  for (int c = fused ? 4 : 0; c < DCP_NUM_CLASSES; ++c) kernels += st.c_begin[c + 1] > st.c_begin[c];
+  for (int s = 0; s < DCP_NUM_PACK_SHAPES; ++s) kernels += st.pk_begin[s + 1] > st.pk_begin[s];
+  bool const fork = kernels > 1;
   if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
-  DcpLaunch a = launch_args(x, st, 0);
-  a.nprob = single_wave;
-  HIP_TRY(x, dcp_launch_cost_fused(a), DCP_EFUNCUSE);
-  for (int c = 4; c < DCP_NUM_CLASSES; ++c)
+  for (int s = 0; s < DCP_NUM_PACK_SHAPES; ++s)
+  {
+    int const np = st.pk_begin[s + 1] - st.pk_begin[s];
+    if (np <= 0) continue;
+    DcpLaunch a = launch_args(x, st, 0);
+    if (fork)
+    {
+      a.stream = x->pstream[s];
+      HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
+    }
+    HIP_TRY(x, dcp_launch_cost_pack(s, a, x->d_packs.p + st.pk_begin[s], np, (uint32_t)x->row_off.back()), DCP_EFUNCUSE);
+    if (fork)
+    {
+      HIP_TRY(x, hipEventRecord(x->pjoin_ev[s], a.stream), DCP_EFUNCUSE);
+      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->pjoin_ev[s], 0), DCP_EFUNCUSE);
+    }
+  }
+  if (fused)
+  {
+    DcpLaunch a = launch_args(x, st, 0);
+    a.nprob = single_wave;
+    if (fork)
+    {
+      a.stream = x->qstream[0];
+      HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
+    }
+    HIP_TRY(x, dcp_launch_cost_fused(a), DCP_EFUNCUSE);
+    if (fork)
+    {
+      HIP_TRY(x, hipEventRecord(x->join_ev[0], a.stream), DCP_EFUNCUSE);
+      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[0], 0), DCP_EFUNCUSE);
+    }
+  }
+  for (int c = fused ? 4 : 0; c < DCP_NUM_CLASSES; ++c)
   {
     DcpLaunch b = launch_args(x, st, c);
     if (b.nprob <= 0) continue;
-    b.stream = x->qstream[c];
-    HIP_TRY(x, hipStreamWaitEvent(b.stream, x->fork_ev, 0), DCP_EFUNCUSE);
+    if (fork)
+    {
+      b.stream = x->qstream[c];
+      HIP_TRY(x, hipStreamWaitEvent(b.stream, x->fork_ev, 0), DCP_EFUNCUSE);
+    }
     HIP_TRY(x, dcp_launch_cost(c, b), DCP_EFUNCUSE);
-    HIP_TRY(x, hipEventRecord(x->join_ev[c], b.stream), DCP_EFUNCUSE);
-    HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
+    if (fork)
+    {
+      HIP_TRY(x, hipEventRecord(x->join_ev[c], b.stream), DCP_EFUNCUSE);
+      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
+    }
   }
   return 0;
 }
@@ -411,6 +510,11 @@ struct dcp_hip *dcp_hip_new(int device)
     ok = ok && hipStreamCreateWithFlags(&x->qstream[c], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&x->join_ev[c], hipEventDisableTiming) == hipSuccess;
   }
+  for (int c = 0; ok && c < DCP_NUM_PACK_SHAPES; ++c)
+  {
+    ok = ok && hipStreamCreateWithFlags(&x->pstream[c], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&x->pjoin_ev[c], hipEventDisableTiming) == hipSuccess;
+  }
   if (!ok)
   {
     dcp_hip_del(x);
@@ -430,6 +534,11 @@ void dcp_hip_del(struct dcp_hip *x)
   {
     if (x->qstream[c]) (void)hipStreamDestroy(x->qstream[c]);
     if (x->join_ev[c]) (void)hipEventDestroy(x->join_ev[c]);
+  }
+  for (int c = 0; c < DCP_NUM_PACK_SHAPES; ++c)
+  {
+    if (x->pstream[c]) (void)hipStreamDestroy(x->pstream[c]);
+    if (x->pjoin_ev[c]) (void)hipEventDestroy(x->pjoin_ev[c]);
   }
   if (x->fork_ev) (void)hipEventDestroy(x->fork_ev);
   if (x->stream) (void)hipStreamDestroy(x->stream);
@@ -460,6 +569,13 @@ static int describe(dcp_hip *x, int K, char const *accession, HostProfile &hp)
   if (cls == DCP_STRIP_CLASS) hp.Kp *= (K + hp.Kp - 1) / hp.Kp; // whole strips
   hp.pool_off = 0;
   hp.accession = accession ? accession : "";
+  hp.pack = dcp_pack_shape_of(K);
+  if (hp.pack >= 0)
+  {
+    int pq = 0, ps = 0;
+    dcp_pack_shape(hp.pack, &pq, &ps);
+    if (hp.W != 1 || ps * pq > hp.Kp) hp.pack = -1; // the shape reads S * Q columns of a row
+  }
   return 0;
 }
 
@@ -886,6 +1002,7 @@ int dcp_hip_stage(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
   memcpy(x->staged_c_begin, st.c_begin, sizeof(st.c_begin));
+  memcpy(x->staged_pk_begin, st.pk_begin, sizeof(st.pk_begin));
   x->staged_cells = st.cells;
   x->staged_n = n;
   return 0;
@@ -897,6 +1014,7 @@ int dcp_hip_run_staged(struct dcp_hip *x, int reps, float *ms, double *cells)
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   Staged st;
   memcpy(st.c_begin, x->staged_c_begin, sizeof(st.c_begin));
+  memcpy(st.pk_begin, x->staged_pk_begin, sizeof(st.pk_begin));
   hipEvent_t e0, e1;
   HIP_TRY(x, hipEventCreate(&e0), DCP_EFUNCUSE);
   HIP_TRY(x, hipEventCreate(&e1), DCP_EFUNCUSE);

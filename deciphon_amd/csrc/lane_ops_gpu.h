@@ -555,3 +555,144 @@ DCP_FN void store_f32_lane0(float *p, lu lane, float v)
 {
   if (lane == 0) *p = v;
 }
+
+// ---- several windows per wavefront (viterbi_pack.h) -----------------------------------------
+// Uniform-per-window values are per GROUP of lanes there, so they are fetched and reduced per lane.
+DCP_FN lu lane_shr(lu x, int s) { return x >> s; }
+DCP_FN lf lneg(lf x) { return -x; }
+
+typedef int dcp_i32x4 __attribute__((ext_vector_type(4)));
+typedef float dcp_f32x2 __attribute__((ext_vector_type(2)));
+typedef float dcp_f32x3 __attribute__((ext_vector_type(3)));
+typedef float dcp_f32x4 __attribute__((ext_vector_type(4)));
+// Structured buffer loads (MUBUF idxen [+ offen]): address = base + vindex * stride + voffset, the multiply
+// done by the address unit.  hipcc has no builtin for them; the LLVM intrinsics are reached by name, which
+// keeps the compiler's own s_waitcnt bookkeeping (an inline-asm load would not have it).
+__device__ float dcp_sbl1(dcp_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.f32");
+__device__ dcp_f32x2 dcp_sbl2(dcp_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v2f32");
+__device__ dcp_f32x3 dcp_sbl3(dcp_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v3f32");
+__device__ dcp_f32x4 dcp_sbl4(dcp_i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4f32");
+
+DCP_FN dcp_i32x4 dcp_make_rsrc(void const *base, uint32_t stride_bytes, uint32_t num_records)
+{
+  uint64_t const a = (uint64_t)base;
+  dcp_i32x4 r;
+  r.x = (int)(uint32_t)a;
+  r.y = (int)(((uint32_t)(a >> 32) & 0xffffu) | (stride_bytes << 16)); // stride: 14 bits from bit 48
+  r.z = (int)num_records;                                             // records of `stride` bytes
+  r.w = 0x00020000;                                                   // as the raw resources of RowSrc
+  return r;
+}
+
+struct PackSrc
+{
+  dcp_i32x4 rows;  // the profile's emission rows: record c = { null[c], bg[c], 0, 0, match[c][0..Kp) }
+  dcp_i32x4 codes; // DcpCodeRow records
+  lu col_off;      // byte offset of the lane's first position inside a record
+};
+
+DCP_FN PackSrc packsrc_make(float const *__restrict__ rows, int Kp, DcpCodeRow const *__restrict__ code_rows,
+                            uint32_t ncode_rows, lu col)
+{
+  PackSrc s;
+  s.rows = dcp_make_rsrc(rows, (uint32_t)(Kp + DCP_ROW_HDR) * 4u, (uint32_t)DCP_TABLE_SIZE);
+  s.codes = dcp_make_rsrc(code_rows, (uint32_t)sizeof(DcpCodeRow), ncode_rows);
+  s.col_off = (col + (uint32_t)DCP_ROW_HDR) * 4u;
+  return s;
+}
+
+// codes of DP row `row` (an index into the code-row array) of the lane's window; rows past the array read 0
+DCP_FN void load_code_row(PackSrc const &s, lu row, lu (&code)[5])
+{
+  dcp_f32x4 const a = dcp_sbl4(s.codes, (int)row, 0, 0, 0);
+  float const b = dcp_sbl1(s.codes, (int)row, 16, 0, 0);
+  code[0] = __float_as_uint(a.x);
+  code[1] = __float_as_uint(a.y);
+  code[2] = __float_as_uint(a.z);
+  code[3] = __float_as_uint(a.w);
+  code[4] = __float_as_uint(b);
+}
+
+DCP_FN void load_pack_hdr(PackSrc const &s, lu code, lf &nil, lf &bg)
+{
+  dcp_f32x2 const h = dcp_sbl2(s.rows, (int)code, 0, 0, 0);
+  nil = h.x;
+  bg = h.y;
+}
+
+template <int Q> DCP_FN void load_pack_q(PackSrc const &s, lu code, lf (&out)[Q]);
+template <> DCP_FN void load_pack_q<1>(PackSrc const &s, lu code, lf (&out)[1])
+{
+  out[0] = dcp_sbl1(s.rows, (int)code, (int)s.col_off, 0, 0);
+}
+template <> DCP_FN void load_pack_q<2>(PackSrc const &s, lu code, lf (&out)[2])
+{
+  dcp_f32x2 const v = dcp_sbl2(s.rows, (int)code, (int)s.col_off, 0, 0);
+  out[0] = v.x;
+  out[1] = v.y;
+}
+template <> DCP_FN void load_pack_q<3>(PackSrc const &s, lu code, lf (&out)[3])
+{
+  dcp_f32x3 const v = dcp_sbl3(s.rows, (int)code, (int)s.col_off, 0, 0);
+  out[0] = v.x;
+  out[1] = v.y;
+  out[2] = v.z;
+}
+template <> DCP_FN void load_pack_q<4>(PackSrc const &s, lu code, lf (&out)[4])
+{
+  dcp_f32x4 const v = dcp_sbl4(s.rows, (int)code, (int)s.col_off, 0, 0);
+  out[0] = v.x;
+  out[1] = v.y;
+  out[2] = v.z;
+  out[3] = v.w;
+}
+template <> DCP_FN void load_pack_q<6>(PackSrc const &s, lu code, lf (&out)[6])
+{
+  dcp_f32x4 const a = dcp_sbl4(s.rows, (int)code, (int)s.col_off, 0, 0);
+  dcp_f32x2 const b = dcp_sbl2(s.rows, (int)code, (int)s.col_off + 16, 0, 0);
+  out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y;
+}
+template <> DCP_FN void load_pack_q<8>(PackSrc const &s, lu code, lf (&out)[8])
+{
+  dcp_f32x4 const a = dcp_sbl4(s.rows, (int)code, (int)s.col_off, 0, 0);
+  dcp_f32x4 const b = dcp_sbl4(s.rows, (int)code, (int)s.col_off + 16, 0, 0);
+  out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+}
+
+// Q consecutive floats of a table row starting at the lane's column
+template <int Q> DCP_FN void load_cols(float const *__restrict__ row, lu col, lf (&out)[Q])
+{
+#pragma unroll
+  for (int q = 0; q < Q; ++q) out[q] = row[col + (uint32_t)q];
+}
+DCP_FN lu load_u32_at(uint32_t const *__restrict__ p, lu i) { return p[i]; }
+DCP_FN lf load_f32_at(float const *__restrict__ p, lu i) { return p[i]; }
+DCP_FN void store_f32_where(float *__restrict__ p, lu i, lm m, lf v)
+{
+  if (m) p[i] = v;
+}
+
+// min over the S lanes of each group, returned to every lane of the group.  Butterfly inside a row of 16
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: DPP operands of v_min_f32); groups of 32 then take
+// the other row of their pair through row_bcast:15 and two readlanes.
+#define DCP_DPP_MIN(v, ctrl) \
+  __builtin_fminf((v), __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, true)))
+template <int S> DCP_FN lf group_min(lf v)
+{
+  v = DCP_DPP_MIN(v, 0xB1);               // quad_perm:[1,0,3,2]
+  v = DCP_DPP_MIN(v, 0x4E);               // quad_perm:[2,3,0,1]
+  if (S >= 8) v = DCP_DPP_MIN(v, 0x141);  // row_half_mirror
+  if (S >= 16) v = DCP_DPP_MIN(v, 0x140); // row_mirror
+  if (S == 32)
+  {
+    // every row is uniform now; rows 1 and 3 take the minimum with the row before them ...
+    lf const t = __int_as_float(
+        __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xa, 0xf, false)); // row_bcast:15
+    lf const u = __builtin_fminf(v, t);
+    // ... and hand it to both rows of their group
+    float const lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 31));
+    float const hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 63));
+    v = (lane_ids() & 32u) ? hi : lo;
+  }
+  return v;
+}

@@ -5,9 +5,21 @@
 // Problems of one launch share the kernel class (Q, W), K <= 64*Q*W.
 #include "lane_ops_gpu.h"
 #include "viterbi_body.h"
+#include "viterbi_pack.h"
 #include "traceback.h"
 #include "viterbi_kernels.h"
 #include "row_replay.h"
+
+// Workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MiB L2 (MI355X_MICROARCH.md, Workgroup
+// dispatch): with the plain blockIdx -> problem mapping the windows of one profile (neighbours in the sorted
+// problem list) land on all eight L2s and every L2 holds the tables of every profile in flight.  This gives
+// XCD x the x-th contiguous eighth of the list instead (the bijective form for any grid size), so an L2 sees
+// an eighth of the profiles.  A speed choice only: nothing depends on where a workgroup runs.
+__device__ __forceinline__ int dcp_xcd_remap(int b, int n)
+{
+  int const q = n >> 3, r = n & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
 
 // (tried: holding Q = 3 / 4 to 96 / 128 VGPRs for 5 / 4 waves per SIMD -- the 6-7 scratch reloads per row cost
 // far more than the occupancy gives: 881 -> 620 GCUPS at K = 173, 1000 -> 878 at K = 256)
@@ -19,8 +31,8 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_kernel(floa
                                                       float const *__restrict__ xt_table,
                                                       float *__restrict__ out, int nprob)
 {
-  int const p = (int)blockIdx.x;
-  if (p >= nprob) return;
+  if ((int)blockIdx.x >= nprob) return;
+  int const p = dcp_xcd_remap((int)blockIdx.x, nprob);
   DcpProblem const pb = problems[p];
   DcpProfileDev const pf = profiles[pb.profile];
   CostWave<Q, W> w;
@@ -39,8 +51,8 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_store_kerne
                                                             unsigned char *__restrict__ arena,
                                                             float *__restrict__ out, int nprob)
 {
-  int const p = (int)blockIdx.x;
-  if (p >= nprob) return;
+  if ((int)blockIdx.x >= nprob) return;
+  int const p = dcp_xcd_remap((int)blockIdx.x, nprob);
   DcpProblem const pb = problems[p];
   DcpProfileDev const pf = profiles[pb.profile];
   CostWave<Q, W, true> w;
@@ -336,8 +348,8 @@ __global__ __launch_bounds__(64) void dcp_cost_kernel_fused(float const *__restr
                                                             float const *__restrict__ xt_table,
                                                             float *__restrict__ out, int nprob)
 {
-  int const p = (int)blockIdx.x;
-  if (p >= nprob) return;
+  if ((int)blockIdx.x >= nprob) return;
+  int const p = dcp_xcd_remap((int)blockIdx.x, nprob);
   DcpProblem const pb = problems[p];
   DcpProfileDev const pf = profiles[pb.profile];
   DcpCodeRow const *codes = code_rows + pb.code_row;
@@ -350,6 +362,23 @@ __global__ __launch_bounds__(64) void dcp_cost_kernel_fused(float const *__restr
   case 3: { CostWave<3, 1> w; w.init(pool, pf, codes, xt); w.run(pb.L, o); break; }
   default: { CostWave<4, 1> w; w.init(pool, pf, codes, xt); w.run(pb.L, o); break; }
   }
+}
+
+// Several windows of one profile per wavefront (viterbi_pack.h): one workgroup = one wavefront = one DcpPack.
+template <int Q, int S>
+__global__ __launch_bounds__(64) void dcp_cost_pack_kernel(float const *__restrict__ pool,
+                                                           DcpProfileDev const *__restrict__ profiles,
+                                                           DcpPack const *__restrict__ packs,
+                                                           DcpCodeRow const *__restrict__ code_rows, uint32_t ncode_rows,
+                                                           float const *__restrict__ xt_table, float *__restrict__ out,
+                                                           int npack)
+{
+  if ((int)blockIdx.x >= npack) return;
+  DcpPack const &pk = packs[dcp_xcd_remap((int)blockIdx.x, npack)];
+  DcpProfileDev const pf = profiles[pk.profile];
+  PackWave<Q, S> w;
+  w.init(pool, pf, code_rows, ncode_rows, xt_table, pk);
+  w.run(pk.Lmax, out, pk);
 }
 
 template <int Q, int W>
@@ -550,7 +579,9 @@ template <bool STORE> static hipError_t launch_strip(DcpLaunch const &a)
 int dcp_class_of(int K)
 {
   if (K < 1) return -1;
-  if (K <= 256) return (K + 63) / 64 - 1; // classes 0..3: one wave, Q = 1..4
+  // classes 0..3: one wave, Q = 1..4.  K = 61..64 take the 128-column layout: the packed cost kernel that runs
+  // them (32 lanes x 3 positions, viterbi_pack.h) reads 96 columns of a row
+  if (K <= 256) return K > 60 && K <= 64 ? 1 : (K + 63) / 64 - 1;
   // Padded sizes 384, 512, 768, 1024, 1536, 2048, 4096.  The cost kernels run them with 6 or 8 positions per
   // lane -- (6,1) (8,1) (6,2) (4,4) (6,4) (8,4) (8,8) -- which halves or quarters the wavefronts that meet at
   // the row barrier; 8 per lane fits 256 VGPRs (two waves per SIMD) only with the transition arrays parked in
@@ -633,6 +664,48 @@ hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t con
   hipLaunchKernelGGL(dcp_traceback_kernel, dim3((unsigned)a.nprob), dim3(64), 0, a.stream, a.pool, a.profiles, a.problems,
                      a.code_rows, a.xt_table, a.arena, steps, step_off, nsteps, a.nprob);
   return hipGetLastError();
+}
+
+// ---- several windows per wavefront: the shapes (lanes per group, positions per lane) by core size ----
+static int const pack_S[DCP_NUM_PACK_SHAPES] = {4, 4, 4, 8, 8, 16, 16, 32, 32};
+static int const pack_Q[DCP_NUM_PACK_SHAPES] = {1, 2, 4, 2, 4, 3, 4, 3, 4};
+
+int dcp_pack_shape_of(int K)
+{
+  for (int i = 0; i < DCP_NUM_PACK_SHAPES; ++i)
+    if (K <= (pack_S[i] - 1) * pack_Q[i]) return i; // the first that holds it costs the fewest instructions per cell
+  return -1;
+}
+
+void dcp_pack_shape(int shape, int *Q, int *S)
+{
+  *Q = pack_Q[shape];
+  *S = pack_S[shape];
+}
+
+template <int Q, int S> static hipError_t launch_pack_qs(DcpLaunch const &a, DcpPack const *packs, int npack, uint32_t ncode_rows)
+{
+  hipLaunchKernelGGL((dcp_cost_pack_kernel<Q, S>), dim3((unsigned)npack), dim3(64), 0, a.stream, a.pool, a.profiles, packs,
+                     a.code_rows, ncode_rows, a.xt_table, a.out, npack);
+  return hipGetLastError();
+}
+
+hipError_t dcp_launch_cost_pack(int shape, DcpLaunch const &a, DcpPack const *packs, int npack, uint32_t ncode_rows)
+{
+  if (npack <= 0) return hipSuccess;
+  switch (shape)
+  {
+  case 0: return launch_pack_qs<1, 4>(a, packs, npack, ncode_rows);
+  case 1: return launch_pack_qs<2, 4>(a, packs, npack, ncode_rows);
+  case 2: return launch_pack_qs<4, 4>(a, packs, npack, ncode_rows);
+  case 3: return launch_pack_qs<2, 8>(a, packs, npack, ncode_rows);
+  case 4: return launch_pack_qs<4, 8>(a, packs, npack, ncode_rows);
+  case 5: return launch_pack_qs<3, 16>(a, packs, npack, ncode_rows);
+  case 6: return launch_pack_qs<4, 16>(a, packs, npack, ncode_rows);
+  case 7: return launch_pack_qs<3, 32>(a, packs, npack, ncode_rows);
+  case 8: return launch_pack_qs<4, 32>(a, packs, npack, ncode_rows);
+  default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t dcp_launch_cost_fused(DcpLaunch const &a)

@@ -60,7 +60,7 @@ def choose_qw(K: int, path: bool = False):
     the cost kernel runs (6, W) / (8, W) on the same padded layout
     (deciphon_amd/csrc/viterbi_kernels.hip: dcp_class_of / dcp_class_shape / dcp_launch_path)."""
     if K <= 256:
-        return max(1, (K + 63) // 64), 1
+        return (2 if 60 < K <= 64 else max(1, (K + 63) // 64)), 1  # 61..64: the 128-column layout (dcp_class_of)
     shapes = ((3, 2), (4, 2), (3, 4), (4, 4), (3, 8), (4, 8), (4, 16)) if path else \
              ((6, 1), (8, 1), (6, 2), (4, 4), (6, 4), (8, 4), (8, 8))
     for Q, W in shapes:

@@ -4,6 +4,7 @@
 #include "lane_ops_emul.h"
 #include "../../deciphon_amd/csrc/viterbi_body.h"
 #include "../../deciphon_amd/csrc/traceback.h"
+#include "../../deciphon_amd/csrc/viterbi_pack.h"
 
 template <int Q, int W>
 static void cost_q(float const *pool, DcpProfileDev const &pf, DcpCodeRow const *codes, int L, float const *xt, float *out)
@@ -191,4 +192,35 @@ extern "C" int emul_replay(float const *pool, DcpProfileDev const *pf, DcpCodeRo
   for (int k = 0; k < pf->K; ++k) nodes[k] = 0;
   for (int l = 1; l <= L; ++l) dcp_replay_row(in, l, acc.data(), xnodes + l, nodes + (size_t)l * pf->K);
   return 0;
+}
+
+// ---- several windows per wavefront (viterbi_pack.h) ----
+template <int Q, int S>
+static void pack_qs(float const *pool, DcpProfileDev const &pf, DcpCodeRow const *codes, uint32_t ncodes, float const *xt_table,
+                    DcpPack const &pk, float *out)
+{
+  static thread_local PackWave<Q, S> w;
+  em_lanes = 64;
+  w.init(pool, pf, codes, ncodes, xt_table, pk);
+  w.run(pk.Lmax, out, pk);
+}
+
+extern "C" int emul_cost_pack(int Q, int S, float const *pool, DcpProfileDev const *pf, DcpCodeRow const *codes,
+                              uint32_t ncodes, float const *xt_table, DcpPack const *pk, float *out)
+{
+  switch (Q * 100 + S)
+  {
+  case 104: pack_qs<1, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 204: pack_qs<2, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 404: pack_qs<4, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 208: pack_qs<2, 8>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 408: pack_qs<4, 8>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 316: pack_qs<3, 16>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 416: pack_qs<4, 16>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 332: pack_qs<3, 32>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 432: pack_qs<4, 32>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 632: pack_qs<6, 32>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 832: pack_qs<8, 32>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  default: return -1;
+  }
 }

@@ -8,6 +8,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "../../deciphon_amd/csrc/dcp_types.h"
+
 #define DCP_FN inline
 #define DCP_WAVE 64
 
@@ -248,3 +250,57 @@ template <int Q> inline void store_nodes_q(uint16_t *row, int K, lu lane, lu con
 
 inline void store_u32_lane0(uint32_t *p, lu, uint32_t v) { *p = v; }
 inline void store_f32_lane0(float *p, lu, float v) { *p = v; }
+
+// ---- several windows per wavefront (viterbi_pack.h): always one 64-lane wave ----
+inline lu lane_shr(lu x, int s) { lu r; EM_FOR r.v[i_] = x.v[i_] >> s; return r; }
+inline lf lneg(lf x) { lf r; EM_FOR r.v[i_] = -x.v[i_]; return r; }
+inline lu operator&(lu a, lu b) { lu r; EM_FOR r.v[i_] = a.v[i_] & b.v[i_]; return r; }
+
+struct PackSrc
+{
+  float const *rows;
+  int Kp;
+  DcpCodeRow const *codes;
+  uint32_t ncodes;
+  lu col;
+};
+inline PackSrc packsrc_make(float const *rows, int Kp, DcpCodeRow const *code_rows, uint32_t ncode_rows, lu col)
+{
+  return PackSrc{rows, Kp, code_rows, ncode_rows, col};
+}
+inline void load_code_row(PackSrc const &s, lu row, lu (&code)[5])
+{
+  for (int t = 0; t < 5; ++t) EM_FOR code[t].v[i_] = row.v[i_] < s.ncodes ? s.codes[row.v[i_]].c[t] : 0u; // range check
+}
+inline void load_pack_hdr(PackSrc const &s, lu code, lf &nil, lf &bg)
+{
+  EM_FOR
+  {
+    float const *r = s.rows + (size_t)code.v[i_] * (size_t)(s.Kp + DCP_ROW_HDR);
+    nil.v[i_] = r[0];
+    bg.v[i_] = r[1];
+  }
+}
+template <int Q> inline void load_pack_q(PackSrc const &s, lu code, lf (&out)[Q])
+{
+  for (int q = 0; q < Q; ++q)
+    EM_FOR out[q].v[i_] = s.rows[(size_t)code.v[i_] * (size_t)(s.Kp + DCP_ROW_HDR) + DCP_ROW_HDR + s.col.v[i_] + q];
+}
+template <int Q> inline void load_cols(float const *row, lu col, lf (&out)[Q])
+{
+  for (int q = 0; q < Q; ++q) EM_FOR out[q].v[i_] = row[col.v[i_] + q];
+}
+inline lu load_u32_at(uint32_t const *p, lu i) { lu r; EM_FOR r.v[i_] = p[i.v[i_]]; return r; }
+inline lf load_f32_at(float const *p, lu i) { lf r; EM_FOR r.v[i_] = p[i.v[i_]]; return r; }
+inline void store_f32_where(float *p, lu i, lm m, lf v) { EM_FOR if (m.v[i_]) p[i.v[i_]] = v.v[i_]; }
+template <int S> inline lf group_min(lf v)
+{
+  lf r;
+  for (int g = 0; g < 64 / S; ++g)
+  {
+    float m = v.v[g * S];
+    for (int i = g * S; i < g * S + S; ++i) m = fminf(m, v.v[i]);
+    for (int i = g * S; i < g * S + S; ++i) r.v[i] = m;
+  }
+  return r;
+}

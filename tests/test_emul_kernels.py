@@ -243,3 +243,83 @@ def test_rows_replayed_from_the_table_give_the_reference_trellis(em, orc):
         assert bits(out[1]) == bits(score)
         assert np.array_equal(xn, xo), (it, K, quant)
         assert np.array_equal(nd, no), (it, K, quant)
+
+
+class Pack(C.Structure):
+    """struct DcpPack (deciphon_amd/csrc/dcp_types.h)."""
+
+    _fields_ = [("profile", C.c_int32), ("Lmax", C.c_int32), ("L", C.c_int32 * 16), ("xt_row", C.c_int32 * 16),
+                ("out", C.c_int32 * 16), ("code_row", C.c_uint32 * 16)]
+
+
+PACK_SHAPES = ((4, 1), (4, 2), (4, 4), (8, 2), (8, 4), (16, 3), (16, 4), (32, 3), (32, 4), (32, 6), (32, 8))  # (S, Q)
+
+
+def run_pack(em, orc, prof, S, Q, seqs, mh=True, h3=False, quant=None):
+    """Windows `seqs` (at most 64 / S) of one profile through PackWave<Q, S>; -> float32 [n][2]."""
+    from dcp_testlib import choose_qw
+
+    G = 64 // S
+    assert len(seqs) <= G and prof.K <= (S - 1) * Q
+    pool, pd = pack_profile(prof, *choose_qw(prof.K))  # the layout of the class the profile belongs to
+    rows, first = [], []
+    for s in seqs:
+        first.append(sum(len(r) for r in rows))
+        rows.append(code_rows(s))
+    rows = np.ascontiguousarray(np.concatenate(rows))
+    smax = max(max(len(s) // 3, 1) for s in seqs)
+    xt = np.zeros((smax + 1, 16), np.float32)
+    for s in range(1, smax + 1):
+        v = orc.xtrans(s, mh, h3)
+        xt[s, :13] = (np.round(v / quant) * quant).astype(np.float32) if quant else v
+    pk = Pack()
+    pk.profile, pk.Lmax = 0, max(len(s) for s in seqs)
+    out = np.full((len(seqs) + 3, 2), np.float32(-7.0), np.float32)  # slots beyond the windows must stay untouched
+    for g, s in enumerate(seqs):
+        pk.L[g], pk.xt_row[g], pk.out[g], pk.code_row[g] = len(s), max(len(s) // 3, 1), g, first[g]
+    assert em.emul_cost_pack(Q, S, _vp(pool), C.byref(pd), _vp(rows), len(rows), _vp(xt), C.byref(pk), _vp(out)) == 0
+    assert np.all(out[len(seqs):] == np.float32(-7.0))
+    return out[: len(seqs)], xt
+
+
+def test_several_windows_per_wavefront(em, orc):
+    """PackWave: groups of 4..32 lanes each run their own window of one profile -- full and partly filled
+    packs, windows of different lengths in one pack (each group captures its results at its own last row),
+    continuous and tie-rich tables, core sizes up to each shape's capacity (S - 1) * Q."""
+    rng = np.random.default_rng(11)
+    for it in range(220):
+        S, Q = PACK_SHAPES[it % len(PACK_SHAPES)]
+        cap = (S - 1) * Q
+        K = int(rng.choice([1, 2, 3, cap // 2 + 1, cap - 1, cap])) if it % 3 else cap
+        K = max(1, min(K, cap))
+        if S * Q > 64 * choose_qw(K)[0]:  # the shape reads S * Q columns: never chosen for so short a row
+            K = cap
+        quant = [None, None, 1.0, 4.0][it % 4]
+        prof = synth_profile(rng, K, quant, [0, 0.05, 0.3][it % 3])
+        G = 64 // S
+        n = G if it % 2 == 0 else int(rng.integers(1, G + 1))
+        same = it % 5 == 0
+        L0 = int(rng.integers(1, 48))
+        seqs = [random_seq(rng, L0 if same else int(rng.integers(1, 48))) for _ in range(n)]
+        out, xt = run_pack(em, orc, prof, S, Q, seqs, it % 2 == 0, it % 4 == 1, quant)
+        for g, s in enumerate(seqs):
+            x = np.ascontiguousarray(xt[max(len(s) // 3, 1), :13])
+            assert bits(out[g, 0]) == bits(orc.null(prof, x, s)), (it, S, Q, K, g, len(s))
+            assert bits(out[g, 1]) == bits(orc.cost(prof, x, s)), (it, S, Q, K, g, len(s))
+
+
+def test_packed_windows_with_long_delete_runs(em, orc):
+    """Nearly free D->D runs cross many lanes -- and must stop at the separator lane of the next group."""
+    rng = np.random.default_rng(12)
+    for S, Q in PACK_SHAPES:
+        K = (S - 1) * Q
+        prof = synth_profile(rng, K)
+        if K > 1:
+            prof.trans[7, 1:] = np.float32(0.01)  # DD
+            prof.trans[3, 1:] = np.float32(0.02)  # MD
+            prof.match[:, K // 3:] += np.float32(30.0)
+        seqs = [random_seq(rng, int(rng.integers(20, 60))) for _ in range(64 // S)]
+        out, xt = run_pack(em, orc, prof, S, Q, seqs)
+        for g, s in enumerate(seqs):
+            x = np.ascontiguousarray(xt[max(len(s) // 3, 1), :13])
+            assert bits(out[g, 0]) == bits(orc.null(prof, x, s)) and bits(out[g, 1]) == bits(orc.cost(prof, x, s)), (S, Q, g)

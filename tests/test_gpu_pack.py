@@ -1,0 +1,107 @@
+"""GPU: the cost pass of short profiles, several windows per wavefront (deciphon_amd/csrc/viterbi_pack.h),
+through the C ABI: against the oracle, and bit for bit against the one-window-per-wavefront kernels
+(DECIPHON_HIP_PACK=0) on the same inputs -- every shape (groups of 4, 8, 16, 32 lanes), packs that are
+full, partly filled and of mixed window lengths, tie-rich tables, and BASELINE configs[2] (massive.hmm is
+a K = 3 profile, c-core/massive.hmm:2-5) at its full size: 1000 x 10 kb reads, 72 chained windows each."""
+import numpy as np
+import pytest
+
+from dcp_testlib import bits, random_seq, synth_profile
+
+pytestmark = pytest.mark.gpu
+
+# (K, shape it lands in): capacities 3, 6, 12, 14, 28, 45, 60, 93, 124
+KS = (1, 2, 3, 4, 6, 7, 12, 13, 14, 20, 28, 29, 45, 46, 60, 61, 64, 65, 93, 94, 100, 124)
+
+
+def _both(engine, wins, monkeypatch):
+    monkeypatch.delenv("DECIPHON_HIP_PACK", raising=False)
+    packed = engine.cost(wins)
+    monkeypatch.setenv("DECIPHON_HIP_PACK", "0")
+    plain = engine.cost(wins)
+    monkeypatch.delenv("DECIPHON_HIP_PACK")
+    assert np.array_equal(packed[0].view(np.uint32), plain[0].view(np.uint32))
+    assert np.array_equal(packed[1].view(np.uint32), plain[1].view(np.uint32))
+    return packed
+
+
+@pytest.mark.parametrize("quant", [None, 2.0])
+def test_every_shape_against_oracle_and_plain_kernels(engine, orc, monkeypatch, quant):
+    rng = np.random.default_rng(17 if quant else 16)
+    profs = [synth_profile(rng, K, quant, [0.0, 0.05][i % 2]) for i, K in enumerate(KS)]
+    profs.append(synth_profile(rng, 125, quant))  # just beyond the largest shape: stays on its own wavefront
+    engine.clear_profiles()
+    for p in profs:
+        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    engine.commit()
+    reads = [random_seq(rng, int(n)) for n in (1, 2, 5, 9, 33, 150, 151, 400, 37, 64, 90, 17)] + \
+            [random_seq(rng, 120) for _ in range(21)]
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    if quant:
+        smax = max(len(r) // 3 for r in reads) + 1
+        table = np.zeros((smax + 1, 13), np.float32)
+        for s in range(1, smax + 1):
+            table[s] = (np.round(orc.xtrans(s, True, False) / quant) * quant).astype(np.float32)
+        engine.set_xtrans_table(table)
+    wins = []
+    for pi in range(len(profs)):
+        for si, r in enumerate(reads):  # 33 windows per profile: no shape's G divides it, and lengths are mixed
+            wins.append((pi, si, 0, len(r)))
+        wins.append((pi, 7, 13, 391))  # a window inside a read
+    try:
+        nul, alt = _both(engine, wins, monkeypatch)
+        for i, (pi, si, a, b) in enumerate(wins):
+            seq = np.ascontiguousarray(reads[si][a:b])
+            xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+            if quant:
+                xt = (np.round(xt / quant) * quant).astype(np.float32)
+            assert bits(nul[i]) == bits(orc.null(profs[pi], xt, seq)), (profs[pi].K, wins[i])
+            assert bits(alt[i]) == bits(orc.cost(profs[pi], xt, seq)), (profs[pi].K, wins[i])
+    finally:
+        engine.set_xtrans_table(np.zeros((0, 13), np.float32))
+
+
+def test_massive_like_at_full_size(engine, orc, monkeypatch):
+    """BASELINE configs[2]: a K = 3 profile x 1000 reads of 10 kb, every window of c-core/window.c
+    (72 per read, 150 nt each): packed == plain on all 72 000 windows, a sample against the oracle."""
+    from deciphon_amd import host
+
+    rng = np.random.default_rng(8)
+    prof = synth_profile(rng, 3)
+    engine.clear_profiles()
+    engine.add_profile(3, prof.trans, prof.match, prof.null, prof.bg)
+    engine.commit()
+    reads = [random_seq(rng, 10000) for _ in range(1000)]
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    chain = []
+    it = host.WindowIter(10000, 3)
+    while (w := it.next()) is not None:
+        chain.append((w[1], w[2]))
+    assert len(chain) == 72
+    wins = np.array([(0, s, a, b) for s in range(len(reads)) for a, b in chain], np.int32)
+    nul, alt = _both(engine, wins, monkeypatch)
+    for i in rng.choice(len(wins), size=300, replace=False):
+        _, s, a, b = (int(v) for v in wins[i])
+        seq = np.ascontiguousarray(reads[s][a:b])
+        xt = orc.xtrans(max((b - a) // 3, 1), True, False)
+        assert bits(nul[i]) == bits(orc.null(prof, xt, seq)) and bits(alt[i]) == bits(orc.cost(prof, xt, seq))
+
+
+def test_many_reads_beyond_the_grid_y_limit(engine, orc):
+    """70 000 short reads in one batch (the y extent of a grid stops at 65 535): codes and scores of reads on
+    both sides of that index against the oracle."""
+    rng = np.random.default_rng(9)
+    prof = synth_profile(rng, 16)
+    engine.clear_profiles()
+    engine.add_profile(16, prof.trans, prof.match, prof.null, prof.bg)
+    engine.commit()
+    reads = [random_seq(rng, 30) for _ in range(70000)]
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    pick = [0, 1, 65534, 65535, 65536, 65537, 69999] + [int(v) for v in rng.integers(0, 70000, size=40)]
+    nul, alt = engine.cost([(0, s, 0, 30) for s in pick])
+    xt = orc.xtrans(10, True, False)
+    for i, s in enumerate(pick):
+        assert bits(nul[i]) == bits(orc.null(prof, xt, reads[s])) and bits(alt[i]) == bits(orc.cost(prof, xt, reads[s])), s
