@@ -64,17 +64,21 @@ DCP_FN lf lf_pin(float x)
   return v;
 }
 
-// min over the 64 lanes, returned to every lane (uniform).  DPP row_shr 1,2,4,8
-// then row_bcast 15 / 31; lanes with no source keep their own value.  hipcc adds
-// no wait states inside asm, so the two required between a VALU write and a DPP
-// read of the same VGPR are written out.
+// min over the 64 lanes, returned to every lane (uniform).  Inside a row of 16 a butterfly -- quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror as DPP operands of v_min_f32, written with the builtin so that the
+// compiler folds each step into one v_min_f32_dpp, places the wait states a DPP read after a VALU write needs
+// and may fill them with other instructions of the row.  Across rows row_bcast:15 / :31, which must leave the
+// other rows alone: the compiler does not fold that form, so those two stay assembly (it adds no wait states
+// inside asm: the two a DPP needs after the VALU write of its source are written out).
+#define DCP_DPP_MIN_ALL(v, ctrl) \
+  __builtin_fminf((v), __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, true)))
 DCP_FN float wave_min(lf v)
 {
-  asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-               "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+  v = DCP_DPP_MIN_ALL(v, 0xB1);  // quad_perm:[1,0,3,2]
+  v = DCP_DPP_MIN_ALL(v, 0x4E);  // quad_perm:[2,3,0,1]
+  v = DCP_DPP_MIN_ALL(v, 0x141); // row_half_mirror
+  v = DCP_DPP_MIN_ALL(v, 0x140); // row_mirror: every row holds its minimum in all lanes
+  asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
                "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
                "s_nop 1"
                : "+v"(v));
@@ -591,13 +595,14 @@ struct PackSrc
   lu col_off;      // byte offset of the lane's first position inside a record
 };
 
+// col_off: byte offset inside a record -- of the lane's first position, or 0 for a lane that reads the header
 DCP_FN PackSrc packsrc_make(float const *__restrict__ rows, int Kp, DcpCodeRow const *__restrict__ code_rows,
-                            uint32_t ncode_rows, lu col)
+                            uint32_t ncode_rows, lu col_off)
 {
   PackSrc s;
   s.rows = dcp_make_rsrc(rows, (uint32_t)(Kp + DCP_ROW_HDR) * 4u, (uint32_t)DCP_TABLE_SIZE);
   s.codes = dcp_make_rsrc(code_rows, (uint32_t)sizeof(DcpCodeRow), ncode_rows);
-  s.col_off = (col + (uint32_t)DCP_ROW_HDR) * 4u;
+  s.col_off = col_off;
   return s;
 }
 
@@ -613,11 +618,14 @@ DCP_FN void load_code_row(PackSrc const &s, lu row, lu (&code)[5])
   code[4] = __float_as_uint(b);
 }
 
-DCP_FN void load_pack_hdr(PackSrc const &s, lu code, lf &nil, lf &bg)
+// lane 0 of every quad to its four lanes (DPP quad_perm:[0,0,0,0]); lane 0 of every group of S to its S lanes
+// (ds_swizzle in bit mode: the source lane is the own lane with the low log2(S) bits cleared -- an LDS-pipe
+// instruction that touches no LDS memory and needs no address)
+DCP_FN lf quad_bcast0(lf x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x00, 0xf, 0xf, true)); }
+template <int S> DCP_FN lf group_bcast0(lf x)
 {
-  dcp_f32x2 const h = dcp_sbl2(s.rows, (int)code, 0, 0, 0);
-  nil = h.x;
-  bg = h.y;
+  if (S == 4) return quad_bcast0(x);
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (~(S - 1)) & 0x1f));
 }
 
 template <int Q> DCP_FN void load_pack_q(PackSrc const &s, lu code, lf (&out)[Q]);
@@ -695,4 +703,52 @@ template <int S> DCP_FN lf group_min(lf v)
     v = (lane_ids() & 32u) ? hi : lo;
   }
   return v;
+}
+
+// Transition arrays of PackWave that a row needs once (in the fold): parked in LDS, one float4 per lane and
+// array (a wave reads 64 consecutive float4s: no bank conflicts), so that they hold no registers meanwhile.
+DCP_FN float4 *pack_stash_mem()
+{
+  __shared__ float4 mem[6 * 64];
+  return mem;
+}
+template <int Q> DCP_FN void pack_stash(int slot, lf const (&v)[Q])
+{
+  static_assert(Q <= 4, "one float4 per lane");
+  pack_stash_mem()[slot * 64 + (int)(threadIdx.x & 63u)] =
+      make_float4(v[0], v[Q > 1 ? 1 : 0], v[Q > 2 ? 2 : 0], v[Q > 3 ? 3 : 0]);
+}
+// All six arrays back at once.  Written as assembly in two halves -- the six ds_read_b128 now, the wait where
+// the values are first needed -- because the compiler would otherwise keep the (loop-invariant) LDS contents
+// in registers across the whole row loop, which is exactly what parking them is meant to avoid.
+struct PackFold
+{
+  dcp_f32x4 a[6];
+};
+DCP_FN void pack_unstash_issue(PackFold &f)
+{
+  uint32_t const addr = (uint32_t)(uintptr_t)(pack_stash_mem() + (threadIdx.x & 63u)); // LDS byte address
+  asm volatile("ds_read_b128 %0, %6\n\t"
+               "ds_read_b128 %1, %6 offset:1024\n\t"
+               "ds_read_b128 %2, %6 offset:2048\n\t"
+               "ds_read_b128 %3, %6 offset:3072\n\t"
+               "ds_read_b128 %4, %6 offset:4096\n\t"
+               "ds_read_b128 %5, %6 offset:5120"
+               : "=v"(f.a[0]), "=v"(f.a[1]), "=v"(f.a[2]), "=v"(f.a[3]), "=v"(f.a[4]), "=v"(f.a[5])
+               : "v"(addr)
+               : "memory");
+}
+template <int Q> DCP_FN void pack_unstash_wait(PackFold &f, lf (&BM)[Q], lf (&MM)[Q], lf (&IM)[Q], lf (&DM)[Q], lf (&II)[Q],
+                                               lf (&MI)[Q])
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.a[4]), "+v"(f.a[5]));
+  lf(*const dst[6])[Q] = {&BM, &MM, &IM, &DM, &II, &MI};
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+  {
+    (*dst[i])[0] = f.a[i].x;
+    if (Q > 1) (*dst[i])[Q > 1 ? 1 : 0] = f.a[i].y;
+    if (Q > 2) (*dst[i])[Q > 2 ? 2 : 0] = f.a[i].z;
+    if (Q > 3) (*dst[i])[Q > 3 ? 3 : 0] = f.a[i].w;
+  }
 }

@@ -39,11 +39,21 @@
 // some M_l[j] plus non-negative delete costs (costs are -log-probabilities), so
 // they never lower the minimum.
 // =============================================================================
+// Delete runs that survive about six to eight positions are common on real profiles (PMC on the minifam bench:
+// 2.5 turns per row with 3 positions per lane): that many positions are covered without asking.
+#ifndef DCP_LAZY_POSITIONS
+#define DCP_LAZY_POSITIONS 6
+#endif
+constexpr int dcp_lazy_turns(int Q) { return Q >= DCP_LAZY_POSITIONS ? 1 : (DCP_LAZY_POSITIONS + Q - 1) / Q; }
+
 // STORE = true additionally writes every row's final values to a DP table in HBM
 // (cells[l][{M,I,D}][Kp] and specials[l][8] = N,B,J,E,C) for the traceback of
 // traceback.h -- the fast path pass.
 template <int Q, int W, bool STORE = false> struct CostWave
 {
+  // lazy D->D turns taken before the first vote: a turn is 2Q + 2 instructions straight-line, a vote costs a
+  // ballot, a scalar branch and the register copies of a loop.  Extra turns change nothing (min is idempotent).
+  static constexpr int TURNS = dcp_lazy_turns(Q);
   // Q = 8: MD, DD, II, MI wait in LDS between their uses (a row needs them for a few instructions
   // each), which brings the kernel from 260 to under 256 VGPRs -- two waves per SIMD instead of one
   static constexpr bool STASH = Q >= 8;
@@ -202,15 +212,22 @@ template <int Q, int W, bool STORE = false> struct CostWave
       for (int q = 1; q < Q; ++q) D[q] = lmin(M[q - 1] + MD[q], D[q - 1] + DD[q]);
       Dsh0 = lane_shift_up_keep(D[Q - 1], shD);
       lf x = Dsh0 + DD[0];
-      lm better = llt(x, D[0]);
-      while (wave_any(better)) // one more lane boundary per turn; a few turns per row on real data
+#pragma unroll
+      for (int turn = 0; turn < TURNS; ++turn)
       {
         D[0] = lmin(D[0], x);
 #pragma unroll
         for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
         Dsh0 = lane_shift_up_keep(D[Q - 1], shD);
         x = Dsh0 + DD[0];
-        better = llt(x, D[0]);
+      }
+      while (wave_any(llt(x, D[0]))) // one more lane boundary per turn
+      {
+        D[0] = lmin(D[0], x);
+#pragma unroll
+        for (int q = 1; q < Q; ++q) D[q] = lmin(D[q], D[q - 1] + DD[q]);
+        Dsh0 = lane_shift_up_keep(D[Q - 1], shD);
+        x = Dsh0 + DD[0];
       }
     }
     else

@@ -32,6 +32,10 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_kernel(floa
                                                       float *__restrict__ out, int nprob)
 {
   if ((int)blockIdx.x >= nprob) return;
+#ifdef DCP_EXP_LDSPAD // timing experiment only: LDS nobody uses, to hold the wavefronts per SIMD down
+  __shared__ float pad[DCP_EXP_LDSPAD / 4];
+  if (nprob < 0) out[0] = pad[threadIdx.x];
+#endif
   int const p = dcp_xcd_remap((int)blockIdx.x, nprob);
   DcpProblem const pb = problems[p];
   DcpProfileDev const pf = profiles[pb.profile];
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(64) void dcp_cost_pack_kernel(float const *__restri
   DcpProfileDev const pf = profiles[pk.profile];
   PackWave<Q, S> w;
   w.init(pool, pf, code_rows, ncode_rows, xt_table, pk);
-  w.run(pk.Lmax, out, pk);
+  w.run(pk.Lmax, out, pk, xt_table);
 }
 
 template <int Q, int W>

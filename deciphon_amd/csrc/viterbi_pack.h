@@ -7,10 +7,14 @@
 // own window of the SAME profile: the per-row work is paid once per G windows and short profiles
 // fill the lanes (K = 3: 16 windows per wavefront instead of 3 busy lanes of 64).
 //
-//   lane = g * S + e.  e = 0 is the group's SEPARATOR: it owns no position, its transition and
-//   emission operands are the +inf padding of the tables, so its M, I, D stay +inf -- which is
+//   lane = g * S + e.  e = 0 is the group's SEPARATOR: it owns no position and its transitions are
+//   the +inf padding of the tables, so its M, I, D stay +inf whatever it adds to them -- which is
 //   exactly what the k-1 neighbour of position 0 must be (shift() injects +inf there,
 //   c-core/intrinsics.h:95-106).  Every k-1 shift is then one plain DPP wave_shr:1 for any S.
+//   What the separator does load, where the other lanes load their match emissions, is the HEADER of
+//   the emission row, { null[c], bg[c] }: the group takes its null and background emissions from it
+//   (DPP quad broadcast to the special-state lanes, ds_swizzle broadcast to the whole group) and a DP
+//   row costs five row loads and two code loads, nothing else.
 //   e = 1 .. S-1 own positions k = (e - 1) * Q + q: a group holds K <= (S - 1) * Q.
 //   The special states ride in lanes e = 0..3 of a separate register (N, J, C and the null
 //   model R), as in CostWave.
@@ -29,57 +33,111 @@
 #endif
 
 #ifndef DCP_INF
-#define DCP_INF (__builtin_inff())
+#error "include viterbi_body.h before viterbi_pack.h"
 #endif
 #ifndef DCP_SL
 #define DCP_SL(P, t) (((P) + 5 - (t)) % 5)
 #endif
 
-// TURNS = lazy D->D turns taken unconditionally before the first vote (a turn is 2Q+2 instructions; a vote
-// costs a ballot, a scalar branch and the copies of a loop: on real profiles the first turns are almost
-// always needed, so they are cheaper straight-line)
-template <int Q, int S, int TURNS = 2> struct PackWave
+// TURNS = lazy D->D turns taken before the first vote (dcp_lazy_turns, viterbi_body.h)
+template <int Q, int S, int TURNS = dcp_lazy_turns(Q)> struct PackWave
 {
   static_assert(S == 4 || S == 8 || S == 16 || S == 32, "groups of 4, 8, 16 or 32 lanes");
   enum { G = 64 / S, CAP = (S - 1) * Q };
-  lu lane, e;           // lane in the wave, lane in its group
-  lf BM[Q], MM[Q], MI[Q], MD[Q], IM[Q], II[Q], DM[Q], DD[Q];
+  // Q = 3, 4: the six transition arrays the fold uses once per row wait in LDS (6 KB per wavefront) instead of
+  // 6Q registers -- the difference between two and three (Q = 4), three and four (Q = 3) wavefronts per SIMD,
+  // and throughput goes with the wavefronts in flight.  MD and DD (the D chain and its turns) stay.
+#ifndef DCP_PACK_STASH
+#define DCP_PACK_STASH 1
+#endif
+  static constexpr bool STASH = DCP_PACK_STASH && Q >= 3 && Q <= 4;
+  lf MD[Q], DD[Q];
   lf Mpre[5][Q], Ipre[5][Q], Spre[5];
-  lf em[5][Q], nil[5], bgv[5];
+  enum { EQ = Q < 2 ? 2 : Q }; // floats a lane loads per emission row: the separator needs two, { null, bg }
+  lf em[5][EQ];
   lu code[5];           // codes of the next row to fetch (per group)
   lf sa, sb, nbjb;      // special transitions by special lane: Xpre = min(E + sa, X + sb); B candidates X + nbjb
   lf X, E;
-  lf EBv, ETv, CTv;
+  lf EBv;
   lf shM, shI, shD;     // destinations of the k-1 shifts (lane 0 of the wave stays +inf)
   lf Xs, Es;            // X and E of the group's own last row
   lu Lg;                // window length of the lane's group (0: idle group)
   lu crow;              // index of the group's code row 0
   PackSrc src;
 
+  lf kBM[STASH ? 1 : Q], kMM[STASH ? 1 : Q], kIM[STASH ? 1 : Q], kDM[STASH ? 1 : Q], kII[STASH ? 1 : Q], kMI[STASH ? 1 : Q];
+  DCP_FN void set_fold_trans(lf const (&BM)[Q], lf const (&MM)[Q], lf const (&IM)[Q], lf const (&DM)[Q],
+                             lf const (&II)[Q], lf const (&MI)[Q])
+  {
+    if constexpr (STASH)
+    {
+      pack_stash<Q>(0, BM);
+      pack_stash<Q>(1, MM);
+      pack_stash<Q>(2, IM);
+      pack_stash<Q>(3, DM);
+      pack_stash<Q>(4, II);
+      pack_stash<Q>(5, MI);
+    }
+    else
+    {
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+      {
+        kBM[q] = BM[q];
+        kMM[q] = MM[q];
+        kIM[q] = IM[q];
+        kDM[q] = DM[q];
+        kII[q] = II[q];
+        kMI[q] = MI[q];
+      }
+    }
+  }
+  DCP_FN void get_fold_trans(PackFold &f, lf (&BM)[Q], lf (&MM)[Q], lf (&IM)[Q], lf (&DM)[Q], lf (&II)[Q], lf (&MI)[Q])
+  {
+    if constexpr (STASH)
+      pack_unstash_wait<Q>(f, BM, MM, IM, DM, II, MI);
+    else
+    {
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+      {
+        BM[q] = kBM[q];
+        MM[q] = kMM[q];
+        IM[q] = kIM[q];
+        DM[q] = kDM[q];
+        II[q] = kII[q];
+        MI[q] = kMI[q];
+      }
+    }
+  }
+
   DCP_FN void fetch_codes(int l) { load_code_row(src, crow + (uint32_t)l, code); }
 
-  // emissions and null/bg of the row whose codes sit in `code`
+  // emissions (separator: null/bg) of the row whose codes sit in `code`
   DCP_FN void fetch_rows()
   {
 #pragma unroll
     for (int t = 0; t < 5; ++t)
     {
-      load_pack_hdr(src, code[t], nil[t], bgv[t]);
-      load_pack_q<Q>(src, code[t], em[t]);
+      load_pack_q<EQ>(src, code[t], em[t]);
     }
   }
 
   DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, DcpCodeRow const *__restrict__ code_rows,
                    uint32_t ncode_rows, float const *__restrict__ xt_table, DcpPack const &pk)
   {
-    lane = lane_ids();
-    e = lane & lu_splat((uint32_t)(S - 1));
+    lu const lane = lane_ids();
+    lu const e = lane & lu_splat((uint32_t)(S - 1)); // lane in its group
     lu const g = lane_shr(lane, S == 4 ? 2 : S == 8 ? 3 : S == 16 ? 4 : 5);
     int const Kp = pf.Kp;
-    // column of the lane's first position; the separator reads the last Q columns of the padded row (+inf)
-    lu const col = lselu(lequ(e, lu_splat(0)), lu_splat((uint32_t)(Kp - Q)), (e - lu_splat(1)) * (uint32_t)Q);
-    src = packsrc_make(pool + pf.rows_off, Kp, code_rows, ncode_rows, col);
+    // column of the lane's first position; the separator takes its transitions from the last Q columns of the
+    // padded arrays (+inf) and reads the header of every emission row (byte offset 0)
+    lm const sep = lequ(e, lu_splat(0));
+    lu const col = lselu(sep, lu_splat((uint32_t)(Kp - Q)), (e - lu_splat(1)) * (uint32_t)Q);
+    src = packsrc_make(pool + pf.rows_off, Kp, code_rows, ncode_rows,
+                       lselu(sep, lu_splat(0), (col + (uint32_t)DCP_ROW_HDR) * 4u));
     float const *__restrict__ trans = pool + pf.trans_off;
+    lf BM[Q], MM[Q], MI[Q], IM[Q], II[Q], DM[Q];
     load_cols<Q>(trans + DCP_BM * Kp, col, BM);
     load_cols<Q>(trans + DCP_MM * Kp, col, MM);
     load_cols<Q>(trans + DCP_MI * Kp, col, MI);
@@ -88,6 +146,7 @@ template <int Q, int S, int TURNS = 2> struct PackWave
     load_cols<Q>(trans + DCP_II * Kp, col, II);
     load_cols<Q>(trans + DCP_DM * Kp, col, DM);
     load_cols<Q>(trans + DCP_DD * Kp, col, DD);
+    set_fold_trans(BM, MM, IM, DM, II, MI);
     Lg = load_u32_at(reinterpret_cast<uint32_t const *>(pk.L), g);
     crow = load_u32_at(pk.code_row, g);
     lu const xrow = load_u32_at(reinterpret_cast<uint32_t const *>(pk.xt_row), g) * (uint32_t)DCP_XT_STRIDE;
@@ -97,8 +156,6 @@ template <int Q, int S, int TURNS = 2> struct PackWave
     lf const RR = load_f32_at(xt_table, xrow + (uint32_t)DCP_RR), SN = load_f32_at(xt_table, xrow + (uint32_t)DCP_SN);
     lf const SB = load_f32_at(xt_table, xrow + (uint32_t)DCP_SB);
     EBv = load_f32_at(xt_table, xrow + (uint32_t)DCP_EB);
-    ETv = load_f32_at(xt_table, xrow + (uint32_t)DCP_ET);
-    CTv = load_f32_at(xt_table, xrow + (uint32_t)DCP_CT);
     // e: 0 = N, 1 = J, 2 = C, 3 = R.  Xpre = min(E + sa, X + sb); B = min(E + EB, N + NB, J + JB)
     sa = lsel(l1, load_f32_at(xt_table, xrow + (uint32_t)DCP_EJ), lsel(l2, load_f32_at(xt_table, xrow + (uint32_t)DCP_EC), inf));
     sb = lsel(l0, load_f32_at(xt_table, xrow + (uint32_t)DCP_NN),
@@ -119,7 +176,7 @@ template <int Q, int S, int TURNS = 2> struct PackWave
       }
     }
 #pragma unroll
-    for (int q = 0; q < Q; ++q) Mpre[0][q] = SB + BM[q];
+    for (int q = 0; q < Q; ++q) Mpre[0][q] = SB + BM[q];  // (BM still in registers here)
     Spre[0] = lsel(l0, lf_splat(0.0f) + SN, lsel(l3, lneg(RR) + RR, inf));
     X = lsel(l3, lneg(RR), inf);
     E = inf;
@@ -130,6 +187,13 @@ template <int Q, int S, int TURNS = 2> struct PackWave
   template <int P> DCP_FN void row(int l, int Lmax)
   {
     lf M[Q], I[Q], D[Q];
+    lf nil[5], bgv[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+    {
+      nil[t] = quad_bcast0(em[t][0]);     // lanes e = 0..3 (the special states): null[c_t] of their group
+      bgv[t] = group_bcast0<S>(em[t][1]); // every lane: bg[c_t] of its group
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {
@@ -159,6 +223,9 @@ template <int Q, int S, int TURNS = 2> struct PackWave
     E = group_min<S>(m);                                   // E_l = min_k M_l[k] (see viterbi_body.h)
     lf const B = lmin(E + EBv, group_min<S>(X + nbjb));    // c-core/viterbi.c:495-496,582-583
 
+    PackFold fold;
+    if constexpr (STASH) pack_unstash_issue(fold); // back from LDS while the D chain runs
+
     // D_l[k] = min(M_l[k-1] + MD[k], D_l[k-1] + DD[k]) (c-core/viterbi.c:538,553-580): serial inside a
     // lane, then carried across lanes until no lane improves (the reference's lazy loop, :569-580)
     D[0] = Msh0 + MD[0];
@@ -185,6 +252,8 @@ template <int Q, int S, int TURNS = 2> struct PackWave
     }
 
     // fold row l into the ring (slot P held row l-5, no longer needed)
+    lf BM[Q], MM[Q], IM[Q], DM[Q], II[Q], MI[Q];
+    get_fold_trans(fold, BM, MM, IM, DM, II, MI);
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {
@@ -202,7 +271,7 @@ template <int Q, int S, int TURNS = 2> struct PackWave
   }
 
   // out[2 * slot] = viterbi_null(), out[2 * slot + 1] = viterbi_cost() of every group's window
-  DCP_FN void run(int Lmax, float *__restrict__ out, DcpPack const &pk)
+  DCP_FN void run(int Lmax, float *__restrict__ out, DcpPack const &pk, float const *__restrict__ xt_table)
   {
     if (Lmax > 0)
     {
@@ -224,10 +293,13 @@ template <int Q, int S, int TURNS = 2> struct PackWave
     if (l <= Lmax) row<3>(l++, Lmax);
     if (l <= Lmax) row<4>(l++, Lmax);
     // lane e = 2 holds C, e = 3 holds R of the group's last row (c-core/viterbi.c:585-586,599,718)
+    lu const lane = lane_ids();
+    lu const e = lane & lu_splat((uint32_t)(S - 1));
     lu const g = lane_shr(lane, S == 4 ? 2 : S == 8 ? 3 : S == 16 ? 4 : 5);
     lu const slot = load_u32_at(reinterpret_cast<uint32_t const *>(pk.out), g);
+    lu const xrow = load_u32_at(reinterpret_cast<uint32_t const *>(pk.xt_row), g) * (uint32_t)DCP_XT_STRIDE;
     lm const active = llt_u(lu_splat(0), Lg);
-    lf const T = lmin(Es + ETv, Xs + CTv);
+    lf const T = lmin(Es + load_f32_at(xt_table, xrow + (uint32_t)DCP_ET), Xs + load_f32_at(xt_table, xrow + (uint32_t)DCP_CT));
     store_f32_where(out, slot * 2u + 1u, land(active, lequ(e, lu_splat(2))), T);
     store_f32_where(out, slot * 2u, land(active, lequ(e, lu_splat(3))), Xs);
   }

@@ -28,7 +28,8 @@ class Window(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "lib", "libdeciphon_hip.so")
+    # DECIPHON_HIP_LIBDIR: a build of the same library elsewhere (kernel experiments: make OUT=<dir> ...)
+    return os.path.join(os.environ.get("DECIPHON_HIP_LIBDIR") or os.path.join(_HERE, "lib"), "libdeciphon_hip.so")
 
 
 def load_library() -> C.CDLL:

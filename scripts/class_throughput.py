@@ -52,9 +52,13 @@ for K in [int(a) for a in (args or "3 16 32 64 100 128 173 192 241 256 400 512 9
     p = real_like(K) if real else synth_profile(rng, K)
     eng.add_profile(p.K, p.trans, p.match, p.null, p.bg)
     eng.commit()
-    nreads = int(min(len(reads), max(512, 3.0e9 / (K * L))))
-    wins = [(0, s, 0, L) for s in range(nreads)]
+    # enough windows for about ten generations of wavefronts whatever the kernel (short profiles run several
+    # windows per wavefront): windows at a few offsets of every read when the reads alone are too few
+    want = int(max(512, min(4.0e9 / (K * L), 2.0e6)))
+    per_read = max(1, (want + len(reads) - 1) // len(reads))
+    nreads = min(len(reads), want)
+    wins = np.array([(0, s, 7 * j, 7 * j + L - 7 * per_read) for j in range(per_read) for s in range(nreads)], np.int32)
     eng.stage(wins)
     eng.run_staged(1)
     ms, cells = eng.run_staged(3)
-    print(f"K={K:5d}  windows={nreads:6d}  {ms / 3:8.2f} ms  {cells / (ms / 3 * 1e-3) / 1e9:7.1f} GCUPS")
+    print(f"K={K:5d}  windows={len(wins):7d}  {ms / 3:8.2f} ms  {cells / (ms / 3 * 1e-3) / 1e9:7.1f} GCUPS")

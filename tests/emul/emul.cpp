@@ -202,7 +202,7 @@ static void pack_qs(float const *pool, DcpProfileDev const &pf, DcpCodeRow const
   static thread_local PackWave<Q, S> w;
   em_lanes = 64;
   w.init(pool, pf, codes, ncodes, xt_table, pk);
-  w.run(pk.Lmax, out, pk);
+  w.run(pk.Lmax, out, pk, xt_table);
 }
 
 extern "C" int emul_cost_pack(int Q, int S, float const *pool, DcpProfileDev const *pf, DcpCodeRow const *codes,

@@ -262,29 +262,22 @@ struct PackSrc
   int Kp;
   DcpCodeRow const *codes;
   uint32_t ncodes;
-  lu col;
+  lu col_off; // byte offset inside a record
 };
-inline PackSrc packsrc_make(float const *rows, int Kp, DcpCodeRow const *code_rows, uint32_t ncode_rows, lu col)
+inline PackSrc packsrc_make(float const *rows, int Kp, DcpCodeRow const *code_rows, uint32_t ncode_rows, lu col_off)
 {
-  return PackSrc{rows, Kp, code_rows, ncode_rows, col};
+  return PackSrc{rows, Kp, code_rows, ncode_rows, col_off};
 }
 inline void load_code_row(PackSrc const &s, lu row, lu (&code)[5])
 {
   for (int t = 0; t < 5; ++t) EM_FOR code[t].v[i_] = row.v[i_] < s.ncodes ? s.codes[row.v[i_]].c[t] : 0u; // range check
 }
-inline void load_pack_hdr(PackSrc const &s, lu code, lf &nil, lf &bg)
-{
-  EM_FOR
-  {
-    float const *r = s.rows + (size_t)code.v[i_] * (size_t)(s.Kp + DCP_ROW_HDR);
-    nil.v[i_] = r[0];
-    bg.v[i_] = r[1];
-  }
-}
+inline lf quad_bcast0(lf x) { lf r; EM_FOR r.v[i_] = x.v[i_ & ~3]; return r; }
+template <int S> inline lf group_bcast0(lf x) { lf r; EM_FOR r.v[i_] = x.v[i_ & ~(S - 1)]; return r; }
 template <int Q> inline void load_pack_q(PackSrc const &s, lu code, lf (&out)[Q])
 {
   for (int q = 0; q < Q; ++q)
-    EM_FOR out[q].v[i_] = s.rows[(size_t)code.v[i_] * (size_t)(s.Kp + DCP_ROW_HDR) + DCP_ROW_HDR + s.col.v[i_] + q];
+    EM_FOR out[q].v[i_] = s.rows[(size_t)code.v[i_] * (size_t)(s.Kp + DCP_ROW_HDR) + s.col_off.v[i_] / 4 + q];
 }
 template <int Q> inline void load_cols(float const *row, lu col, lf (&out)[Q])
 {
@@ -303,4 +296,21 @@ template <int S> inline lf group_min(lf v)
     for (int i = g * S; i < g * S + S; ++i) r.v[i] = m;
   }
   return r;
+}
+
+static thread_local lf em_pack_stash[6][8];
+template <int Q> inline void pack_stash(int slot, lf const (&v)[Q]) { for (int q = 0; q < Q; ++q) em_pack_stash[slot][q] = v[q]; }
+struct PackFold { int unused; };
+inline void pack_unstash_issue(PackFold &) {}
+template <int Q> inline void pack_unstash_wait(PackFold &, lf (&BM)[Q], lf (&MM)[Q], lf (&IM)[Q], lf (&DM)[Q], lf (&II)[Q], lf (&MI)[Q])
+{
+  for (int q = 0; q < Q; ++q)
+  {
+    BM[q] = em_pack_stash[0][q];
+    MM[q] = em_pack_stash[1][q];
+    IM[q] = em_pack_stash[2][q];
+    DM[q] = em_pack_stash[3][q];
+    II[q] = em_pack_stash[4][q];
+    MI[q] = em_pack_stash[5][q];
+  }
 }
