@@ -360,6 +360,48 @@ int DcpDbReader::read_protein(int i, DcpProtein &x) const
   return 0;
 }
 
+// nuclt_dist_unpack (c-core/nuclt_dist.c:22-31): array(2){ nuclt lprobs (4 f32), codon marginals (125 f32) }
+static bool read_nuclt_dist(Cur &c, float *nucltp, float *codonm)
+{
+  Tok t = next(c);
+  if (t.kind != K_ARRAY || t.i != 2) return false;
+  return read_f32array(c, 4, nucltp) && read_f32array(c, 125, codonm);
+}
+
+int DcpDbReader::read_decoder(int i, DcpDecoder &x) const
+{
+  if (!data_ || i < 0 || i >= num_proteins()) return DCP_EINVALPART;
+  Cur c{data_ + offsets_[(size_t)i], data_ + offsets_[(size_t)i + 1]};
+  int64_t v = 0;
+  std::string text;
+  if (!expect_map(c, 10)) return DCP_EFDATA;
+  if (!expect_key(c, "accession") || !read_str(c, text, 32)) return DCP_EFDATA;
+  if (!expect_key(c, "gencode") || !read_int(c, v)) return DCP_EFDATA;
+  x.gencode = (int)v;
+  if (!expect_key(c, "consensus") || !read_str(c, text, DCP_MODEL_MAX + 1)) return DCP_EFDATA;
+  if (!expect_key(c, "core_size") || !read_int(c, v)) return DCP_EFDATA;
+  if (v <= 0 || v > DCP_MODEL_MAX) return DCP_ELARGECORESIZE;
+  x.core_size = (int)v;
+  x.epsilon = header_.epsilon;
+  size_t const K = (size_t)x.core_size;
+  x.nucltp.assign((K + 3) * 4, 0.0f);
+  x.codonm.assign((K + 3) * 125, 0.0f);
+  if (!expect_key(c, "null_nuclt_dist") || !read_nuclt_dist(c, x.nucltp.data(), x.codonm.data())) return DCP_ENUCLTDUNPACK;
+  if (!expect_key(c, "null_emission") || !skip(c)) return DCP_EFDATA;
+  if (!expect_key(c, "bg_nuclt_dist") || !read_nuclt_dist(c, x.nucltp.data() + 4, x.codonm.data() + 125))
+    return DCP_ENUCLTDUNPACK;
+  if (!expect_key(c, "bg_emission") || !skip(c)) return DCP_EFDATA;
+  if (!expect_key(c, "nodes") || !expect_map(c, (int64_t)(K + 1) * 3)) return DCP_EFDATA;
+  for (size_t n = 0; n <= K; ++n)
+  {
+    if (!expect_key(c, "nuclt_dist") || !read_nuclt_dist(c, x.nucltp.data() + 4 * (2 + n), x.codonm.data() + 125 * (2 + n)))
+      return DCP_ENUCLTDUNPACK;
+    if (!expect_key(c, "trans") || !skip(c)) return DCP_EFDATA;
+    if (!expect_key(c, "emission") || !skip(c)) return DCP_EFDATA;
+  }
+  return c.ok ? 0 : DCP_EFDATA;
+}
+
 int DcpDbReader::read_protein_head(int i, int &core_size, std::string &accession) const
 {
   if (!data_ || i < 0 || i >= num_proteins()) return DCP_EINVALPART;

@@ -27,6 +27,19 @@ struct DcpProtein
   std::vector<float> BMk;           // [K]
 };
 
+// What decoder_setup (c-core/decoder.c:21-36) takes from a protein: the nucleotide and codon distributions of
+// the null model, the background and every node.  imm_nuclt_lprob is 4 log-probabilities (A, C, G, T);
+// imm_codon_marg is the 5 x 5 x 5 table of codon marginals, index 4 = "any nucleotide" (third-party imm).
+struct DcpDecoder
+{
+  int gencode = 0;
+  int core_size = 0;
+  float epsilon = 0;
+  // [K + 3]: 0 = null, 1 = background, 2 + n = node n (n = 0..K)
+  std::vector<float> nucltp; // [(K + 3) * 4]
+  std::vector<float> codonm; // [(K + 3) * 125]
+};
+
 struct DcpDbHeader
 {
   int magic_number = 0;
@@ -58,6 +71,8 @@ public:
   int read_protein(int i, DcpProtein &out) const;
   // only accession and core size (the first keys of the record): cheap pre-scan
   int read_protein_head(int i, int &core_size, std::string &accession) const;
+  // the distributions codon decoding needs (the emission and transition arrays are stepped over)
+  int read_decoder(int i, DcpDecoder &out) const;
 
 private:
   uint8_t const *data_ = nullptr;

@@ -415,8 +415,8 @@ int launch_all(dcp_hip *x, Staged const &st, bool path)
   return 0;
 }
 
-// Cost pass.  The packed kernels (short profiles, several windows per wavefront) go out first, one stream per
-// shape.  Of the rest, a small launch that mixes single-wave classes goes out as ONE fused kernel (classes 0..3
+// Cost pass.  The packed kernels (short profiles, several windows per wavefront) have one stream per shape.
+// Of the rest, a small launch that mixes single-wave classes goes out as ONE fused kernel (classes 0..3
 // are contiguous in the sorted problem list); large launches keep one kernel per class, which fills the GPU
 // by itself and has its own register budget.  Everything is forked from and joined back into x->stream.
 int launch_cost_all(dcp_hip *x, Staged const &st)
@@ -430,21 +430,25 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
   for (int s = 0; s < DCP_NUM_PACK_SHAPES; ++s) kernels += st.pk_begin[s + 1] > st.pk_begin[s];
   bool const fork = kernels > 1;
   if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
-  for (int s = 0; s < DCP_NUM_PACK_SHAPES; ++s)
+  // Launch order = start order (the hardware runs a few queues side by side and takes kernels as they come):
+  // the classes with the fewest, longest-running workgroups go first -- multi-wave groups, then 8, 6, 4, 3
+  // positions per lane -- and the packed kernels with their many short wavefronts last, where they fill what
+  // the tails of the others leave idle.  (The other way round the K > 384 classes ran alone at the end of a
+  // Pfam-shaped step: 33 + 50 ms of 456, profiles/r02_b.)
+  for (int c = DCP_NUM_CLASSES - 1; c >= (fused ? 4 : 0); --c)
   {
-    int const np = st.pk_begin[s + 1] - st.pk_begin[s];
-    if (np <= 0) continue;
-    DcpLaunch a = launch_args(x, st, 0);
+    DcpLaunch b = launch_args(x, st, c);
+    if (b.nprob <= 0) continue;
     if (fork)
     {
-      a.stream = x->pstream[s];
-      HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
+      b.stream = x->qstream[c];
+      HIP_TRY(x, hipStreamWaitEvent(b.stream, x->fork_ev, 0), DCP_EFUNCUSE);
     }
-    HIP_TRY(x, dcp_launch_cost_pack(s, a, x->d_packs.p + st.pk_begin[s], np, (uint32_t)x->row_off.back()), DCP_EFUNCUSE);
+    HIP_TRY(x, dcp_launch_cost(c, b), DCP_EFUNCUSE);
     if (fork)
     {
-      HIP_TRY(x, hipEventRecord(x->pjoin_ev[s], a.stream), DCP_EFUNCUSE);
-      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->pjoin_ev[s], 0), DCP_EFUNCUSE);
+      HIP_TRY(x, hipEventRecord(x->join_ev[c], b.stream), DCP_EFUNCUSE);
+      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
     }
   }
   if (fused)
@@ -463,20 +467,21 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
       HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[0], 0), DCP_EFUNCUSE);
     }
   }
-  for (int c = fused ? 4 : 0; c < DCP_NUM_CLASSES; ++c)
+  for (int s = DCP_NUM_PACK_SHAPES - 1; s >= 0; --s)
   {
-    DcpLaunch b = launch_args(x, st, c);
-    if (b.nprob <= 0) continue;
+    int const np = st.pk_begin[s + 1] - st.pk_begin[s];
+    if (np <= 0) continue;
+    DcpLaunch a = launch_args(x, st, 0);
     if (fork)
     {
-      b.stream = x->qstream[c];
-      HIP_TRY(x, hipStreamWaitEvent(b.stream, x->fork_ev, 0), DCP_EFUNCUSE);
+      a.stream = x->pstream[s];
+      HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
     }
-    HIP_TRY(x, dcp_launch_cost(c, b), DCP_EFUNCUSE);
+    HIP_TRY(x, dcp_launch_cost_pack(s, a, x->d_packs.p + st.pk_begin[s], np, (uint32_t)x->row_off.back()), DCP_EFUNCUSE);
     if (fork)
     {
-      HIP_TRY(x, hipEventRecord(x->join_ev[c], b.stream), DCP_EFUNCUSE);
-      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
+      HIP_TRY(x, hipEventRecord(x->pjoin_ev[s], a.stream), DCP_EFUNCUSE);
+      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->pjoin_ev[s], 0), DCP_EFUNCUSE);
     }
   }
   return 0;

@@ -79,6 +79,29 @@ int dcp_db_partition_bounds(struct dcp_db const *x, int nparts, int balanced, in
   return 0;
 }
 
+int dcp_db_read_nuclt_dist(struct dcp_db const *x, int i, float *nucltp, float *codonm, int *gencode)
+{
+  if (!x) return DCP_EFUNCUSE;
+  DcpDecoder d;
+  int rc = x->reader.read_decoder(i, d);
+  if (rc) return rc;
+  if (nucltp) memcpy(nucltp, d.nucltp.data(), d.nucltp.size() * sizeof(float));
+  if (codonm) memcpy(codonm, d.codonm.data(), d.codonm.size() * sizeof(float));
+  if (gencode) *gencode = d.gencode;
+  return 0;
+}
+
+int dcp_decode_quasi_codon(float epsilon, float const *nucltp4, float const *codonm125, uint8_t const *nt, int n,
+                           uint8_t codon[3])
+{
+  if (!nucltp4 || !codonm125 || !nt || !codon) return DCP_EFUNCUSE;
+  for (int i = 0; i < n && i < 5; ++i)
+    if (nt[i] > 3) return DCP_ESEQABC;
+  return dcp_decode_codon(epsilon, nucltp4, codonm125, nt, n, codon) ? 0 : DCP_EDECODON;
+}
+
+char dcp_gencode_amino_of(int gencode_id, uint8_t const codon[3]) { return dcp_gencode_amino(gencode_id, codon); }
+
 int dcp_partition_bounds_of(int n, int32_t const *core_sizes, int nparts, int balanced, int32_t *first)
 {
   if (n < 0 || !first || (balanced && n > 0 && !core_sizes)) return DCP_EFUNCUSE;

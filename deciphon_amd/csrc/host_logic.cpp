@@ -354,3 +354,114 @@ void dcp_partition_bounds(int n, int32_t const *core_sizes, int nparts, bool bal
   }
   first[nparts] = n;
 }
+
+// ---- quasi-codon decoding (see host_logic.h) ----
+namespace
+{
+
+// how many single-base deletions of codon x leave the pair (a, b)
+inline int del1(uint8_t const x[3], int a, int b) { return (x[1] == a && x[2] == b) + (x[0] == a && x[2] == b) + (x[0] == a && x[1] == b); }
+inline int has(uint8_t const x[3], int a) { return (x[0] == a) + (x[1] == a) + (x[2] == a); }
+
+double frag_given_codon(double e, double const p[4], uint8_t const x[3], uint8_t const *z, int n)
+{
+  double const f = 1.0 - e;
+  switch (n)
+  {
+  case 1: return e * e * f * f / 3.0 * has(x, z[0]);
+  case 2:
+    return 2.0 * e * f * f * f / 3.0 * del1(x, z[0], z[1]) +
+           e * e * e * f / 3.0 * (p[z[0]] * has(x, z[1]) + p[z[1]] * has(x, z[0]));
+  case 3:
+  {
+    double v = f * f * f * f * (x[0] == z[0] && x[1] == z[1] && x[2] == z[2]);
+    v += 4.0 * e * e * f * f / 9.0 *
+         (p[z[0]] * del1(x, z[1], z[2]) + p[z[1]] * del1(x, z[0], z[2]) + p[z[2]] * del1(x, z[0], z[1]));
+    return v + e * e * e * e * p[z[0]] * p[z[1]] * p[z[2]];
+  }
+  case 4:
+  {
+    double one = 0, two = 0;
+    for (int j = 0; j < 4; ++j)
+    {
+      uint8_t r[3];
+      for (int t = 0, k = 0; t < 4; ++t)
+        if (t != j) r[k++] = z[t];
+      one += p[z[j]] * (x[0] == r[0] && x[1] == r[1] && x[2] == r[2]);
+    }
+    for (int i = 0; i < 4; ++i)
+      for (int j = i + 1; j < 4; ++j)
+      {
+        uint8_t r[2];
+        for (int t = 0, k = 0; t < 4; ++t)
+          if (t != i && t != j) r[k++] = z[t];
+        two += p[z[i]] * p[z[j]] * del1(x, r[0], r[1]);
+      }
+    return e * f * f * f / 2.0 * one + e * e * e * f / 9.0 * two;
+  }
+  case 5:
+  {
+    double v = 0;
+    for (int i = 0; i < 5; ++i)
+      for (int j = i + 1; j < 5; ++j)
+      {
+        uint8_t r[3];
+        for (int t = 0, k = 0; t < 5; ++t)
+          if (t != i && t != j) r[k++] = z[t];
+        v += p[z[i]] * p[z[j]] * (x[0] == r[0] && x[1] == r[1] && x[2] == r[2]);
+      }
+    return e * e * f * f / 10.0 * v;
+  }
+  default: return 0.0;
+  }
+}
+
+} // namespace
+
+bool dcp_decode_codon(float epsilon, float const nucltp[4], float const codonm[125], uint8_t const *z, int n,
+                      uint8_t codon[3])
+{
+  if (n < 1 || n > 5) return false;
+  double p[4];
+  for (int i = 0; i < 4; ++i) p[i] = exp((double)nucltp[i]);
+  double best = 0.0;
+  bool found = false;
+  for (uint8_t a = 0; a < 4; ++a)
+    for (uint8_t b = 0; b < 4; ++b)
+      for (uint8_t c = 0; c < 4; ++c)
+      {
+        uint8_t const x[3] = {a, b, c};
+        double const joint = exp((double)codonm[a * 25 + b * 5 + c]) * frag_given_codon((double)epsilon, p, x, z, n);
+        if (joint > best)
+        {
+          best = joint;
+          codon[0] = a;
+          codon[1] = b;
+          codon[2] = c;
+          found = true;
+        }
+      }
+  return found;
+}
+
+char dcp_gencode_amino(int id, uint8_t const codon[3])
+{
+  // NCBI translation tables, amino acids in TCAG order of the three codon positions
+  struct Table { int id; char const *aa; };
+  static Table const tables[] = {
+      {1, "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},
+      {2, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG"},
+      {3, "FFLLSSSSYY**CCWWTTTTPPPPHHQQRRRRIIMMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},
+      {4, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},
+      {5, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSSSVVVVAAAADDEEGGGG"},
+      {6, "FFLLSSSSYYQQCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},
+      {9, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG"},
+      {10, "FFLLSSSSYY**CCCWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},
+      {11, "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},
+      {12, "FFLLSSSSYY**CC*WLLLSPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},
+  };
+  static int const tcag[4] = {2, 1, 3, 0}; // our indices A, C, G, T -> position in T, C, A, G
+  for (Table const &t : tables)
+    if (t.id == id) return t.aa[tcag[codon[0]] * 16 + tcag[codon[1]] * 4 + tcag[codon[2]]];
+  return 0;
+}

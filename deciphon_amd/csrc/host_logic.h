@@ -58,3 +58,25 @@ inline float dcp_lrt(float null_loglik, float alt_loglik) { return -2 * (null_lo
 // sum of core sizes comes closest to p/nparts of the total -- DP cells are proportional to K, not to the
 // number of profiles.
 void dcp_partition_bounds(int n, int32_t const *core_sizes, int nparts, bool balanced, int32_t *first);
+
+// ---- quasi-codon decoding: decoder_decode (c-core/decoder.c:38-58) + imm_gencode_decode ----
+// The arithmetic is third-party imm's imm_frame_cond_decode (absent here; unpinned HEAD in the reference's CI).
+// Restated from the published quasi-codon model, whose marginal form the pressed tables themselves confirm
+// (tests/test_decoder.py: sum over codons of P(codon) P(z | codon) reproduces the emission table of every
+// node of the reference's minifam.dcp to fp32 rounding):  z = 1..5 nucleotides emitted for codon x under
+// per-base error rate e --
+//   |z| = 1: e^2 (1-e)^2 / 3       * #{ i : x_i = z_1 }
+//   |z| = 2: 2 e (1-e)^3 / 3       * #{ deletions of one base of x that leave z }
+//          + e^3 (1-e) / 3         * ( p(z_1) #{ i : x_i = z_2 } + p(z_2) #{ i : x_i = z_1 } )
+//   |z| = 3: (1-e)^4 [x = z] + 4 e^2 (1-e)^2 / 9 * sum_j p(z_j) #{ deletions of one base of x that leave z \ j }
+//          + e^4 p(z_1) p(z_2) p(z_3)
+//   |z| = 4: e (1-e)^3 / 2 * sum_j p(z_j) [x = z \ j] + e^3 (1-e) / 9 * sum_{i<j} p(z_i) p(z_j) #{ deletions of one base of x that leave z \ i,j }
+//   |z| = 5: e^2 (1-e)^2 / 10 * sum_{i<j} p(z_i) p(z_j) [x = z \ i,j]
+// with p = the state's nucleotide distribution; the decoded codon maximises P(x) P(z | x) over the 64 codons,
+// P(x) from the state's codon marginals (first maximum in A,C,G,T order).  Parity with imm is pinned only by
+// the reference's committed products.tsv (three hits, every step an exact codon): unpinned beyond that.
+// z: nucleotide indices 0..3, n = 1..5.  Returns false when no codon has positive probability.
+bool dcp_decode_codon(float epsilon, float const nucltp[4], float const codonm[125], uint8_t const *z, int n,
+                      uint8_t codon[3]);
+// imm_gencode_decode: amino acid of a codon under NCBI translation table `gencode_id`; 0 when the table is unknown
+char dcp_gencode_amino(int gencode_id, uint8_t const codon[3]);

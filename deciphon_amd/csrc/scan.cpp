@@ -59,6 +59,10 @@ struct dcp_scan
   int index_offset = 0;   // global index of local profile 0 (workload_index, c-core/workload.c:95)
   std::string abc_name = "dna";
   std::vector<std::string> products;
+  // quasi-codon decoding (c-core/decoder.c): the database stays mapped, and the distributions of a profile are
+  // read from it the first time one of its windows yields a hit
+  std::unique_ptr<DcpDbReader> db;
+  std::vector<std::shared_ptr<DcpDecoder const>> decoders; // by local profile
 };
 
 struct dcp_press
@@ -123,11 +127,15 @@ struct Row
   std::string text;
 };
 
-// product_thread_add_match (c-core/product_thread.c:40-79) without HMMER / decoder
+// product_thread_add_match + write_match (c-core/product_thread.c:40-79,112-148) without HMMER: every step of the
+// hit as "<nucleotides>,<state>,<codon>,<amino>", the last two from decoder_decode / imm_gencode_decode
+// (c-core/match.c:66-89, c-core/decoder.c:38-58) for the emitting states.  *rc receives DCP_EDECODON when a step
+// cannot be decoded (the reference fails the scan there).
 std::string format_row(dcp_batch::Seq const &seq, int window, int wstart, int wstop, DcpHit const &hit,
                        char const *accession, char const *abc, float lrt, std::vector<int32_t> const &ids,
-                       std::vector<int32_t> const &sizes)
+                       std::vector<int32_t> const &sizes, DcpDecoder const &dec, std::atomic<int> *rc)
 {
+  char const *sym = seq.has_u ? "ACGU" : "ACGT";
   char head[256];
   snprintf(head, sizeof head, "%ld\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%s\t%.1f\tnan\t", seq.id, window, wstart, wstop, 0,
            hit.hit_start, hit.hit_stop, accession, abc, (double)lrt);
@@ -140,11 +148,41 @@ std::string format_row(dcp_batch::Seq const &seq, int window, int wstart, int ws
     if (i > hit.begin_step) out += ';';
     char name[8];
     dcp_state_name(ids[(size_t)i], name);
-    out.append(seq.text, (size_t)(wstart + pos), (size_t)sizes[(size_t)i]);
+    int const n = sizes[(size_t)i], id = ids[(size_t)i];
+    out.append(seq.text, (size_t)(wstart + pos), (size_t)n);
     out += ',';
     out += name;
-    out += ",,"; // codon and amino: c-core/decoder.c is out of scope
-    pos += sizes[(size_t)i];
+    out += ',';
+    if (!dcp_state_is_mute(id))
+    {
+      // insert states decode against the background, match states against their node, N / J / C against the
+      // null model (c-core/decoder.c:43-49)
+      int const kind = id >> 14, k = (id & 0x3FFF) - 1;
+      size_t const entry = kind == 1 ? 1 : kind == 0 ? 2 + (size_t)k : 0;
+      uint8_t codon[3] = {0, 0, 0};
+      bool const ok = kind <= 1 && (k < 0 || k > dec.core_size)
+                          ? false
+                          : dcp_decode_codon(dec.epsilon, dec.nucltp.data() + 4 * entry, dec.codonm.data() + 125 * entry,
+                                             seq.nt.data() + wstart + pos, n, codon);
+      char const amino = ok ? dcp_gencode_amino(dec.gencode, codon) : 0;
+      if (!ok || !amino)
+      {
+        int expected = 0;
+        rc->compare_exchange_strong(expected, !ok ? DCP_EDECODON : DCP_EGENCODEID);
+      }
+      else
+      {
+        out += sym[codon[0]];
+        out += sym[codon[1]];
+        out += sym[codon[2]];
+        out += ',';
+        out += amino;
+      }
+      if (!ok || !amino) out += ',';
+    }
+    else
+      out += ',';
+    pos += n;
   }
   return out;
 }
@@ -188,6 +226,9 @@ int setup_common(dcp_scan *x, char const *dbfile, int device, int index, int npa
     x->index_offset = first[(size_t)index];
     x->num_proteins = first[(size_t)index + 1] - first[(size_t)index];
   }
+  x->db.reset(new DcpDbReader);
+  if ((rc = x->db->open(dbfile))) return raise(rc, __func__, dbfile);
+  x->decoders.clear();
   if (x->eng) dcp_hip_del(x->eng);
   x->eng = dcp_hip_new(device);
   if (!x->eng) return raise(DCP_EFUNCUSE, __func__, "no usable HIP device (there is no CPU fallback)");
@@ -295,8 +336,11 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     float lrt;
     DcpHit hit;
     std::vector<int32_t> ids, sizes;
+    std::shared_ptr<DcpDecoder const> dec;
   };
   std::deque<std::vector<Row>> formatted;
+  std::atomic<int> decode_rc{0};
+  x->decoders.resize((size_t)std::max(dcp_hip_num_profiles(x->eng), 0));
   struct Joiner
   {
     std::vector<std::thread> threads;
@@ -389,6 +433,13 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
           j.wstart = pr.win.start;
           j.wstop = pr.win.stop;
           j.lrt = lrts[h];
+          if (!x->decoders[(size_t)pr.profile]) // decoder_setup, c-core/decoder.c:21-36
+          {
+            auto dec = std::make_shared<DcpDecoder>();
+            if ((rc = x->db->read_decoder(x->index_offset + pr.profile, *dec))) return raise(rc, __func__);
+            x->decoders[(size_t)pr.profile] = dec;
+          }
+          j.dec = x->decoders[(size_t)pr.profile];
           jobs->push_back(std::move(j));
         }
         if (!jobs->empty())
@@ -396,7 +447,8 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
           formatted.emplace_back(jobs->size());
           std::vector<Row> *out = &formatted.back();
           dcp_scan const *scan = x;
-          formatters.add(std::thread([jobs, out, scan, batch]() {
+          std::atomic<int> *drc = &decode_rc;
+          formatters.add(std::thread([jobs, out, scan, batch, drc]() {
             std::atomic<size_t> next_job{0};
             auto work = [&]() {
               for (size_t k = next_job.fetch_add(1); k < jobs->size(); k = next_job.fetch_add(1))
@@ -406,7 +458,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
                 (*out)[k] = Row{j.profile, j.seq, j.widx,
                                 format_row(seq, j.widx, j.wstart, j.wstop, j.hit,
                                            dcp_hip_profile_accession(scan->eng, j.profile), scan->abc_name.c_str(),
-                                           j.lrt, j.ids, j.sizes)};
+                                           j.lrt, j.ids, j.sizes, *j.dec, drc)};
               }
             };
             unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
@@ -428,6 +480,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   }
 
   formatters.join();
+  if (decode_rc) return raise(decode_rc, __func__); // c-core/match.c:66-89 fails the scan the same way
   for (std::vector<Row> &part : formatted)
     for (Row &r : part) rows.push_back(std::move(r));
   ph.rows += ph.lap();

@@ -17,6 +17,9 @@
 // an eighth of the profiles.  A speed choice only: nothing depends on where a workgroup runs.
 __device__ __forceinline__ int dcp_xcd_remap(int b, int n)
 {
+  // a launch of about one generation of wavefronts keeps the plain order: there the eighths would be uneven in
+  // time (windows of different profiles take different time) with nothing left to even them out
+  if (n < 16384) return b;
   int const q = n >> 3, r = n & 7, x = b & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }

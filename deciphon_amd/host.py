@@ -33,6 +33,10 @@ def _lib():
     L.dcp_db_protein_offset.restype = C.c_int64
     L.dcp_db_protein_core_size.argtypes = [vp, i32, C.POINTER(i32)]
     L.dcp_db_read_protein.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.c_char_p, C.c_char_p]
+    L.dcp_db_read_nuclt_dist.argtypes = [vp, i32, vp, vp, C.POINTER(i32)]
+    L.dcp_decode_quasi_codon.argtypes = [C.c_float, vp, vp, vp, i32, vp]
+    L.dcp_gencode_amino_of.argtypes = [i32, vp]
+    L.dcp_gencode_amino_of.restype = C.c_char
     L.dcp_db_core_sizes.argtypes = [vp, vp]
     L.dcp_db_partition_bounds.argtypes = [vp, i32, i32, vp]
     L.dcp_partition_bounds_of.argtypes = [i32, vp, i32, i32, vp]
@@ -123,8 +127,16 @@ class Database:
         rc = self.lib.dcp_db_read_protein(self.h, i, p(trans), p(emission), p(BMk), p(null), p(bg), acc, cons)
         if rc:
             raise HipError(rc)
+        nucltp = np.zeros((K + 3, 4), np.float32)
+        codonm = np.zeros((K + 3, 125), np.float32)
+        gencode = C.c_int(0)
+        rc = self.lib.dcp_db_read_nuclt_dist(self.h, i, p(nucltp), p(codonm), C.byref(gencode))
+        if rc:
+            raise HipError(rc)
+        # nucltp / codonm: entry 0 = null model, 1 = background, 2 + n = node n (what decoder_setup takes)
         return dict(core_size=K, accession=acc.value.decode(), consensus=cons.value.decode(), trans=trans,
-                    emission=emission, BMk=BMk, null_emission=null, bg_emission=bg)
+                    emission=emission, BMk=BMk, null_emission=null, bg_emission=bg, gencode=gencode.value,
+                    nucltp=nucltp, codonm=codonm)
 
 
 def partition_bounds(core_sizes, nparts: int, balanced: bool = False) -> np.ndarray:
@@ -199,3 +211,22 @@ def state_is_mute(state_id: int) -> bool:
 
 def lrt(null_loglik, alt_loglik) -> np.float32:
     return np.float32(_lib().dcp_lrt_of(float(null_loglik), float(alt_loglik)))
+
+
+def decode_quasi_codon(epsilon: float, nucltp, codonm, nt) -> np.ndarray:
+    """decoder_decode (c-core/decoder.c:38-58): codon (3 nucleotide indices) behind the 1..5 nucleotides nt."""
+    a = np.ascontiguousarray(nucltp, np.float32)
+    b = np.ascontiguousarray(codonm, np.float32)
+    z = np.ascontiguousarray(nt, np.uint8)
+    out = np.zeros(3, np.uint8)
+    rc = _lib().dcp_decode_quasi_codon(float(epsilon), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                       z.ctypes.data_as(C.c_void_p), len(z), out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise HipError(rc)
+    return out
+
+
+def gencode_amino(gencode_id: int, codon) -> str:
+    c = np.ascontiguousarray(codon, np.uint8)
+    r = _lib().dcp_gencode_amino_of(int(gencode_id), c.ctypes.data_as(C.c_void_p))
+    return r.decode() if r != b"\0" else ""

@@ -41,23 +41,30 @@ def _finish(K, src, seeds, accession):
     emission = np.empty((K + 1, TABLE_SIZE), np.float32)
     trans = np.empty((K + 1, 7), np.float32)
     BMk = np.empty(K, np.float32)
+    nucltp = np.zeros((K + 3, 4), np.float32)    # 0 = null, 1 = background, 2 + n = node n
+    codonm = np.zeros((K + 3, 125), np.float32)
+    s0 = seeds[src[0][0]]
+    if "nucltp" in s0:
+        nucltp[:2], codonm[:2] = s0["nucltp"][:2], s0["codonm"][:2]
     cons = []
     for k, (p, i) in enumerate(src):
         s = seeds[p]
         emission[k] = s["emission"][i]
         trans[k] = s["trans"][i]
         BMk[k] = s["BMk"][i]
+        if "nucltp" in s:
+            nucltp[2 + k], codonm[2 + k] = s["nucltp"][2 + i], s["codonm"][2 + i]
         cons.append(s["consensus"][i] if i < len(s["consensus"]) else "x")
+    nucltp[2 + K], codonm[2 + K] = nucltp[1 + K], codonm[1 + K]
     # the end of a model as the reference builds it (c-core/model.c; visible in any pressed profile):
     # node K duplicates node K-1, whose MD and DD are impossible and whose DM is certain
     emission[K] = emission[K - 1]
     trans[K - 1, 2] = trans[K - 1, 6] = -np.inf
     trans[K - 1, 5] = 0.0
     trans[K] = trans[K - 1]
-    s0 = seeds[src[0][0]]
-    return dict(core_size=K, accession=accession, gencode=1, consensus="".join(cons), trans=trans,
-                emission=emission, BMk=BMk, null_emission=np.array(s0["null_emission"], np.float32),
-                bg_emission=np.array(s0["bg_emission"], np.float32))
+    return dict(core_size=K, accession=accession, gencode=int(s0.get("gencode", 1)), consensus="".join(cons),
+                trans=trans, emission=emission, BMk=BMk, null_emission=np.array(s0["null_emission"], np.float32),
+                bg_emission=np.array(s0["bg_emission"], np.float32), nucltp=nucltp, codonm=codonm)
 
 
 def resample_protein(seeds, K: int, rng, accession: str, mean_run: int = 30) -> dict:
@@ -203,13 +210,18 @@ def _f32(a, legacy: bool) -> bytes:
 def pack_protein(p: dict, legacy: bool = False) -> bytes:
     """protein_pack, c-core/protein.c:234-281."""
     K = int(p["core_size"])
-    nuclt = _arr(2) + _f32(np.zeros(4, np.float32), legacy) + _f32(np.zeros(125, np.float32), legacy)
+    nucltp = p.get("nucltp", np.zeros((K + 3, 4), np.float32))
+    codonm = p.get("codonm", np.zeros((K + 3, 125), np.float32))
+
+    def nuclt(j):  # nuclt_dist_pack, c-core/nuclt_dist.c:13-20
+        return _arr(2) + _f32(nucltp[j], legacy) + _f32(codonm[j], legacy)
+
     kn, kt, ke = _s("nuclt_dist"), _s("trans"), _s("emission")
-    nodes = b"".join(kn + nuclt + kt + _f32(p["trans"][i], legacy) + ke + _f32(p["emission"][i], legacy)
+    nodes = b"".join(kn + nuclt(2 + i) + kt + _f32(p["trans"][i], legacy) + ke + _f32(p["emission"][i], legacy)
                      for i in range(K + 1))
     return (_map(10) + _s("accession") + _s(p["accession"]) + _s("gencode") + _u(int(p.get("gencode", 1)))
-            + _s("consensus") + _s(p["consensus"]) + _s("core_size") + _u(K) + _s("null_nuclt_dist") + nuclt
-            + _s("null_emission") + _f32(p["null_emission"], legacy) + _s("bg_nuclt_dist") + nuclt
+            + _s("consensus") + _s(p["consensus"]) + _s("core_size") + _u(K) + _s("null_nuclt_dist") + nuclt(0)
+            + _s("null_emission") + _f32(p["null_emission"], legacy) + _s("bg_nuclt_dist") + nuclt(1)
             + _s("bg_emission") + _f32(p["bg_emission"], legacy) + _s("nodes") + _map((K + 1) * 3) + nodes
             + _s("BMk") + _f32(p["BMk"], legacy))
 

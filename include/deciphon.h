@@ -10,8 +10,9 @@
  *  - HMMER rescoring (the h3daemon TCP client of c-core/hmmer.c) is out of scope:
  *    `port` is ignored, no row is dropped for lack of a HMMER hit, the `evalue`
  *    column holds `nan` and no hmmer/ directory with .h3r files is written.
- *  - quasi-codon decoding (c-core/decoder.c, third-party imm) is out of scope: the
- *    codon and amino fields of the `match` column are left empty.
+ *  - the codon and amino fields of the `match` column come from a restatement of third-party
+ *    imm's imm_frame_cond_decode (csrc/host_logic.h), pinned by the reference's committed
+ *    products.tsv only.
  *  - dcp_press_* needs the absent third-party imm/hmmer_reader libraries; the
  *    symbols exist and fail with DCP_EFUNCUSE.
  */

@@ -31,6 +31,17 @@ int dcp_db_protein_core_size(struct dcp_db const *, int i, int *core_size);
 int dcp_db_read_protein(struct dcp_db const *, int i, float *node_trans, float *node_emission, float *BMk,
                         float *null_lprob, float *bg_lprob, char *accession, char *consensus);
 
+/* The distributions quasi-codon decoding uses (decoder_setup, c-core/decoder.c:21-36): for entry 0 = null model,
+ * 1 = background, 2 + n = node n (n = 0..K): nucltp[(K+3)*4] nucleotide log-probabilities and codonm[(K+3)*125]
+ * codon marginals (5 x 5 x 5, index 4 = any nucleotide).  Any pointer may be NULL. */
+int dcp_db_read_nuclt_dist(struct dcp_db const *, int i, float *nucltp, float *codonm, int *gencode);
+/* decoder_decode (c-core/decoder.c:38-58; arithmetic of third-party imm's imm_frame_cond_decode restated, see
+ * csrc/host_logic.h): the codon (nucleotide indices) that most likely produced the n = 1..5 nucleotides nt under
+ * error rate epsilon.  Returns 0, or DCP_EDECODON.  dcp_gencode_amino_of: imm_gencode_decode, 0 = unknown table. */
+int dcp_decode_quasi_codon(float epsilon, float const *nucltp4, float const *codonm125, uint8_t const *nt, int n,
+                           uint8_t codon[3]);
+char dcp_gencode_amino_of(int gencode_id, uint8_t const codon[3]);
+
 /* partition_size (c-core/partition_size.c:13-16): proteins of partition idx out of nparts */
 long dcp_partition_size(long nelems, long nparts, long idx);
 /* core sizes of all proteins (read from the protein heads; nothing else of a protein is touched) */

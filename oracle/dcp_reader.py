@@ -29,6 +29,8 @@ class Protein:
     trans: np.ndarray  # [(K+1), 7]
     emission: np.ndarray  # [(K+1), 1364] node-major
     BMk: np.ndarray  # [K]
+    nucltp: np.ndarray = None  # [(K+3), 4]: 0 = null, 1 = background, 2 + n = node n (decoder_setup, c-core/decoder.c:21-36)
+    codonm: np.ndarray = None  # [(K+3), 125]
 
 
 @dataclasses.dataclass
@@ -86,11 +88,16 @@ def read_dcp(path: str) -> Database:
         assert len(nodes) == (K + 1) * 3
         trans = np.empty((K + 1, TRANS_SIZE), dtype=np.float32)
         emission = np.empty((K + 1, TABLE_SIZE), dtype=np.float32)
+        nucltp = np.empty((K + 3, 4), dtype=np.float32)
+        codonm = np.empty((K + 3, 125), dtype=np.float32)
+        for j, key in enumerate(("null_nuclt_dist", "bg_nuclt_dist")):
+            nucltp[j], codonm[j] = _f32(d[key][0]), _f32(d[key][1])
         for i in range(K + 1):
-            (k0, _), (k1, t), (k2, e) = nodes[3 * i : 3 * i + 3]
+            (k0, nd), (k1, t), (k2, e) = nodes[3 * i : 3 * i + 3]
             assert (k0, k1, k2) == ("nuclt_dist", "trans", "emission")
             trans[i] = _f32(t)
             emission[i] = _f32(e)
+            nucltp[2 + i], codonm[2 + i] = _f32(nd[0]), _f32(nd[1])
         proteins.append(
             Protein(
                 accession=d["accession"],
@@ -102,6 +109,8 @@ def read_dcp(path: str) -> Database:
                 trans=trans,
                 emission=emission,
                 BMk=_f32(d["BMk"]),
+                nucltp=nucltp,
+                codonm=codonm,
             )
         )
     assert len(proteins) == len(sizes)

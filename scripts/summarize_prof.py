@@ -69,7 +69,7 @@ per_kernel_valu = defaultdict(float)
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "dcp_cost_kernel" not in r["Kernel_Name"] and "dcp_strip_kernel" not in r["Kernel_Name"]:
+            if "dcp_cost" not in r["Kernel_Name"] and "dcp_strip_kernel" not in r["Kernel_Name"]:
                 continue
             if r["Counter_Name"] == "FETCH_SIZE":
                 fetch += float(r["Counter_Value"])

@@ -149,12 +149,15 @@ def bits(x) -> int:
     return int(np.float32(x).view(np.uint32))
 
 
-def oracle_scan(orc, proteins, reads, multi_hits, hmmer3_compat, threads: int = 1):
+def oracle_scan(orc, proteins, reads, multi_hits, hmmer3_compat, threads: int = 1, epsilon: float = 0.01):
     """thread_run + process_window (c-core/thread.c:49-207) on the CPU oracle, without HMMER: the rows of
-    products.tsv in the reference's order.  proteins: objects with the fields of oracle.dcp_reader.Protein;
+    products.tsv in the reference's order, codon and amino fields from oracle.pydecode (write_match,
+    c-core/product_thread.c:112-148).  proteins: objects with the fields of oracle.dcp_reader.Protein;
     reads: [(id, text)].  threads > 1 spreads the proteins over a thread pool (ctypes drops the GIL)."""
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import pydecode
 
     encoded = [(sid, text, orc.encode(text)) for sid, text in reads]
 
@@ -177,7 +180,15 @@ def oracle_scan(orc, proteins, reads, multi_hits, hmmer3_compat, threads: int = 
                 w.last_hit_pos = last
                 pos, cells = hit[0], []
                 for st, sz in zip(ids[hit[2] : hit[3]], sizes[hit[2] : hit[3]]):
-                    cells.append(f"{text[w.start + pos : w.start + pos + sz]},{orc.state_name(st)},,")
+                    st, sz = int(st), int(sz)
+                    dec = ","
+                    if sz:  # an emitting state: insert -> background, match -> its node, N / J / C -> null model
+                        kind, k = st >> 14, (st & 0x3FFF) - 1
+                        entry = 1 if kind == 1 else 2 + k if kind == 0 else 0
+                        codon, amino = pydecode.decode(epsilon, prot.nucltp[entry], prot.codonm[entry],
+                                                       seq[pos : pos + sz])
+                        dec = "".join("ACGT"[v] for v in codon) + "," + amino
+                    cells.append(f"{text[w.start + pos : w.start + pos + sz]},{orc.state_name(st)},{dec}")
                     pos += sz
                 rows.append(f"{sid}\t{w.idx}\t{w.start}\t{w.stop}\t0\t{hit[0]}\t{hit[1]}\t{prot.accession}\tdna\t"
                             f"{lrt:.1f}\tnan\t" + ";".join(cells))
