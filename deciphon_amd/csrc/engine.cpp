@@ -188,6 +188,7 @@ struct dcp_hip
   DevBuf<unsigned char> d_trellis; // trellises of the literal path pass
   std::vector<dcp_hip_window> path_wins; // the windows of the last dcp_hip_path
   int path_redone = 0;                   // how many of them needed the literal pass
+  DevBuf<uint32_t> d_hits;         // dcp_hip_cost_hits: count, then (window, lrt bits) pairs
   DevBuf<uint32_t> d_steps, d_compact;
   DevBuf<int64_t> d_step_off, d_compact_off;
   DevBuf<int32_t> d_nsteps;
@@ -954,6 +955,41 @@ int dcp_hip_cost(struct dcp_hip *x, int n, struct dcp_hip_window const *w, float
     fprintf(stderr, "dcp_hip_cost: %d windows; stage %.1f ms, kernels %.1f ms, fetch %.1f ms\n", n, ms(t0, t1), ms(t1, t2),
             ms(t2, t3));
   }
+  return 0;
+}
+
+int dcp_hip_cost_hits(struct dcp_hip *x, int n, struct dcp_hip_window const *w, int *nhits, int32_t *hit_window,
+                      float *hit_lrt)
+{
+  if (!x || !nhits || (n > 0 && (!hit_window || !hit_lrt))) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  *nhits = 0;
+  Staged st;
+  int rc = stage(x, n, w, ARENA_NONE, st);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, x->d_hits.reserve(1 + 2 * (size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, hipMemsetAsync(x->d_hits.p, 0, sizeof(uint32_t), x->stream), DCP_EFUNCUSE);
+  if ((rc = launch_cost_all(x, st))) return rc;
+  HIP_TRY(x, dcp_launch_lrt_filter(x->d_out.p, n, x->d_hits.p, x->stream), DCP_EFUNCUSE);
+  uint32_t count = 0;
+  HIP_TRY(x, hipMemcpyAsync(&count, x->d_hits.p, sizeof count, hipMemcpyDeviceToHost, x->stream), DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  if (count == 0) return 0;
+  std::vector<uint32_t> pairs(2 * (size_t)count);
+  HIP_TRY(x, hipMemcpyAsync(pairs.data(), x->d_hits.p + 1, pairs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  std::vector<std::pair<uint32_t, uint32_t>> hits(count);
+  for (uint32_t i = 0; i < count; ++i) hits[i] = {pairs[2 * (size_t)i], pairs[2 * (size_t)i + 1]};
+  std::sort(hits.begin(), hits.end()); // the device appends in no particular order
+  for (uint32_t i = 0; i < count; ++i)
+  {
+    hit_window[i] = (int32_t)hits[i].first;
+    memcpy(hit_lrt + i, &hits[i].second, sizeof(float));
+  }
+  *nhits = (int)count;
   return 0;
 }
 

@@ -388,22 +388,21 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
       ++rounds;
       nwindows += wins.size();
       ph.windows += ph.lap();
-      std::vector<float> nul(wins.size()), alt(wins.size());
-      if ((rc = dcp_hip_cost(x->eng, (int)wins.size(), wins.data(), nul.data(), alt.data())))
+      // c-core/thread.c:114-121: null and alternative scores, lrt and its filter -- all on the device; what comes
+      // back are the windows that go on to the path pass
+      std::vector<int32_t> hit_index(wins.size());
+      std::vector<float> lrts(wins.size());
+      int nh = 0;
+      if ((rc = dcp_hip_cost_hits(x->eng, (int)wins.size(), wins.data(), &nh, hit_index.data(), lrts.data())))
         return raise(rc, __func__, dcp_hip_strerror(x->eng));
       ph.cost += ph.lap();
-
-      // c-core/thread.c:114-121
-      std::vector<dcp_hip_window> hits;
-      std::vector<size_t> hit_of;
-      std::vector<float> lrts;
-      for (size_t i = 0; i < wins.size(); ++i)
+      std::vector<dcp_hip_window> hits((size_t)nh);
+      std::vector<size_t> hit_of((size_t)nh);
+      lrts.resize((size_t)nh);
+      for (int h = 0; h < nh; ++h)
       {
-        float const l = dcp_lrt(-nul[i], -alt[i]);
-        if (!isfinite(l) || l < 0) continue;
-        hits.push_back(wins[i]);
-        hit_of.push_back(i);
-        lrts.push_back(l);
+        hit_of[(size_t)h] = (size_t)hit_index[(size_t)h];
+        hits[(size_t)h] = wins[hit_of[(size_t)h]];
       }
       // one path pass per round (the engine slices it by the HBM its DP tables take)
       for (size_t h0 = 0; h0 < hits.size();)

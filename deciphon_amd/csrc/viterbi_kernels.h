@@ -19,9 +19,10 @@ int dcp_class_of(int K);                      // -1 when K is not covered
 void dcp_class_shape(int cls, int *Q, int *W);
 
 // Several windows per wavefront (viterbi_pack.h), cost pass of short profiles: shape i runs groups of S lanes
-// with Q positions per lane, (S - 1) * Q positions at most -- (4,1) (4,2) (4,4) (8,2) (8,4) (16,3) (16,4) (32,3)
-// (32,4): K <= 3, 6, 12, 14, 28, 45, 60, 93, 124.  The tables keep the layout of the class the profile belongs to.
-#define DCP_NUM_PACK_SHAPES 9
+// with Q positions per lane, (S - 1) * Q positions at most -- (4,1) (4,2) (4,4) (8,2) (8,4) (16,2) (16,3) (16,4)
+// (32,2) (32,3) (32,4): K <= 3, 6, 12, 14, 28, 30, 45, 60, 62, 93, 124.  The tables keep the layout of the class
+// the profile belongs to.
+#define DCP_NUM_PACK_SHAPES 11
 int dcp_pack_shape_of(int K); // -1: no shape holds K
 void dcp_pack_shape(int shape, int *Q, int *S);
 
@@ -54,6 +55,9 @@ hipError_t dcp_launch_compact_steps(uint32_t const *steps, int64_t const *step_o
                                     uint32_t *out, int n, hipStream_t stream);
 // packs of one shape: one wavefront each; a.problems is not used
 hipError_t dcp_launch_cost_pack(int shape, DcpLaunch const &a, DcpPack const *packs, int npack, uint32_t ncode_rows);
+// lrt of every window from out[2n] = (null, alt); hits[0] = number of windows with a finite lrt >= 0 (zeroed by
+// the caller), then (window, lrt bits) pairs, unordered
+hipError_t dcp_launch_lrt_filter(float const *out, int n, uint32_t *hits, hipStream_t stream);
 // every problem of classes 0..3 (single-wave) in one launch
 hipError_t dcp_launch_cost_fused(DcpLaunch const &a);
 hipError_t dcp_launch_encode(unsigned char const *nt, int64_t const *seq_off, int64_t const *row_off, int nseq,

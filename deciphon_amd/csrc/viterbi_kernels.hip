@@ -3,6 +3,8 @@
 // One workgroup per (profile x window) problem: a single wavefront for K <= 256
 // (Q = 1..4 positions per lane), W = 2..16 wavefronts of Q = 4 beyond that.
 // Problems of one launch share the kernel class (Q, W), K <= 64*Q*W.
+#include <stdlib.h>
+
 #include "lane_ops_gpu.h"
 #include "viterbi_body.h"
 #include "viterbi_pack.h"
@@ -528,6 +530,42 @@ __global__ void dcp_unzip_kernel(DcpProfileDev const *__restrict__ profiles, Dcp
   nsteps[pb.out] = bad ? -1 : (int32_t)n;
 }
 
+// The filter of process_window (c-core/thread.c:118-121) on the device: lrt = -2 * (null - alt) of every window
+// (c-core/lrt.h:6-9, the same fp32 operations), and the windows that go on to the path pass -- lrt finite and
+// >= 0 -- appended to a list: hits[0] counts them, then (window, lrt bits) pairs, in no particular order (the
+// host sorts the few that there are).
+__global__ void dcp_lrt_filter_kernel(float const *__restrict__ out, int n, uint32_t *__restrict__ hits)
+{
+  int const i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  bool keep = false;
+  float lrt = 0.0f;
+  if (i < n)
+  {
+    float const null_loglik = -out[2 * (size_t)i], alt_loglik = -out[2 * (size_t)i + 1];
+    lrt = -2 * (null_loglik - alt_loglik);
+    keep = lrt >= 0.0f && lrt < __builtin_inff(); // finite (not NaN, not +inf) and not negative
+  }
+  unsigned long long const mask = __ballot(keep);
+  if (!mask) return;
+  int const lane = (int)(threadIdx.x & 63);
+  uint32_t base = 0;
+  if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(hits, (uint32_t)__popcll(mask));
+  base = (uint32_t)__shfl((int)base, __ffsll((long long)mask) - 1);
+  if (keep)
+  {
+    uint32_t const at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    hits[1 + 2 * (size_t)at] = (uint32_t)i;
+    hits[2 + 2 * (size_t)at] = __float_as_uint(lrt);
+  }
+}
+
+hipError_t dcp_launch_lrt_filter(float const *out, int n, uint32_t *hits, hipStream_t stream)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dcp_lrt_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, n, hits);
+  return hipGetLastError();
+}
+
 // Packs the steps of all windows back to back (window i: compact_off[i] .. compact_off[i+1])
 // so that one small D2H copy carries every path: the per-window buffers are sized for the
 // worst case and mostly empty.
@@ -674,11 +712,14 @@ hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t con
 }
 
 // ---- several windows per wavefront: the shapes (lanes per group, positions per lane) by core size ----
-static int const pack_S[DCP_NUM_PACK_SHAPES] = {4, 4, 4, 8, 8, 16, 16, 32, 32};
-static int const pack_Q[DCP_NUM_PACK_SHAPES] = {1, 2, 4, 2, 4, 3, 4, 3, 4};
+static int const pack_S[DCP_NUM_PACK_SHAPES] = {4, 4, 4, 8, 8, 16, 16, 16, 32, 32, 32};
+static int const pack_Q[DCP_NUM_PACK_SHAPES] = {1, 2, 4, 2, 4, 2, 3, 4, 2, 3, 4};
 
 int dcp_pack_shape_of(int K)
 {
+  // DECIPHON_HIP_PACK_PREFER=<shape>: that shape for every profile it holds (throughput experiments)
+  static int const prefer = getenv("DECIPHON_HIP_PACK_PREFER") ? atoi(getenv("DECIPHON_HIP_PACK_PREFER")) : -1;
+  if (prefer >= 0 && prefer < DCP_NUM_PACK_SHAPES && K <= (pack_S[prefer] - 1) * pack_Q[prefer]) return prefer;
   for (int i = 0; i < DCP_NUM_PACK_SHAPES; ++i)
     if (K <= (pack_S[i] - 1) * pack_Q[i]) return i; // the first that holds it costs the fewest instructions per cell
   return -1;
@@ -707,10 +748,12 @@ hipError_t dcp_launch_cost_pack(int shape, DcpLaunch const &a, DcpPack const *pa
   case 2: return launch_pack_qs<4, 4>(a, packs, npack, ncode_rows);
   case 3: return launch_pack_qs<2, 8>(a, packs, npack, ncode_rows);
   case 4: return launch_pack_qs<4, 8>(a, packs, npack, ncode_rows);
-  case 5: return launch_pack_qs<3, 16>(a, packs, npack, ncode_rows);
-  case 6: return launch_pack_qs<4, 16>(a, packs, npack, ncode_rows);
-  case 7: return launch_pack_qs<3, 32>(a, packs, npack, ncode_rows);
-  case 8: return launch_pack_qs<4, 32>(a, packs, npack, ncode_rows);
+  case 5: return launch_pack_qs<2, 16>(a, packs, npack, ncode_rows);
+  case 6: return launch_pack_qs<3, 16>(a, packs, npack, ncode_rows);
+  case 7: return launch_pack_qs<4, 16>(a, packs, npack, ncode_rows);
+  case 8: return launch_pack_qs<2, 32>(a, packs, npack, ncode_rows);
+  case 9: return launch_pack_qs<3, 32>(a, packs, npack, ncode_rows);
+  case 10: return launch_pack_qs<4, 32>(a, packs, npack, ncode_rows);
   default: return hipErrorInvalidValue;
   }
 }

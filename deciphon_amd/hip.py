@@ -68,6 +68,7 @@ def load_library() -> C.CDLL:
     L.dcp_hip_xtrans.argtypes = [i32, i32, i32, vp]
     L.dcp_hip_xtrans.restype = None
     L.dcp_hip_cost.argtypes = [vp, i32, vp, vp, vp]
+    L.dcp_hip_cost_hits.argtypes = [vp, i32, vp, C.POINTER(i32), vp, vp]
     L.dcp_hip_cost_bench.argtypes = [vp, i32, vp, i32, i32, f32p, C.POINTER(C.c_double), vp, vp]
     L.dcp_hip_stage.argtypes = [vp, i32, vp]
     L.dcp_hip_run_staged.argtypes = [vp, i32, f32p, C.POINTER(C.c_double)]
@@ -234,6 +235,16 @@ class Engine:
         alt = np.zeros(n, dtype=np.float32)
         self._check(self.lib.dcp_hip_cost(self.h, n, arr, _p(nul), _p(alt)))
         return nul, alt
+
+    def cost_hits(self, windows):
+        """-> (indices, lrt) of the windows whose lrt is finite and >= 0: the cost pass followed by
+        process_window's filter (c-core/thread.c:118-121), both on the device."""
+        n, arr = self._windows(windows)
+        idx = np.zeros(max(n, 1), dtype=np.int32)
+        lrt = np.zeros(max(n, 1), dtype=np.float32)
+        nh = C.c_int(0)
+        self._check(self.lib.dcp_hip_cost_hits(self.h, n, arr, C.byref(nh), _p(idx), _p(lrt)))
+        return idx[: nh.value].copy(), lrt[: nh.value].copy()
 
     def cost_bench(self, windows, warmup: int, reps: int):
         """-> (ms per launch, cells per launch, null_cost, alt_cost), timed with HIP events."""

@@ -104,6 +104,12 @@ struct dcp_hip_window
  * into log-likelihoods and forms lrt = -2*(null - alt), c-core/lrt.h:6-9). */
 int dcp_hip_cost(struct dcp_hip *, int n, struct dcp_hip_window const *, float *null_cost, float *alt_cost);
 
+/* The same followed by process_window's filter (c-core/thread.c:118-121) on the device: only the windows
+ * whose lrt = -2 * (null - alt) (c-core/lrt.h:6-9) is finite and >= 0 come back -- *nhits of them, their indices
+ * into the window array in increasing order and their lrt; hit_window and hit_lrt must hold n entries. */
+int dcp_hip_cost_hits(struct dcp_hip *, int n, struct dcp_hip_window const *, int *nhits, int32_t *hit_window,
+                      float *hit_lrt);
+
 /* viterbi_path + trellis_unzip for n windows (c-core/thread.c:124-126).  Results
  * stay valid until the next dcp_hip_path / dcp_hip_del.
  * The steps come from a fast pass (cost pass with the DP values kept in HBM + a traceback

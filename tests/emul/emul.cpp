@@ -215,6 +215,8 @@ extern "C" int emul_cost_pack(int Q, int S, float const *pool, DcpProfileDev con
   case 404: pack_qs<4, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
   case 208: pack_qs<2, 8>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
   case 408: pack_qs<4, 8>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 216: pack_qs<2, 16>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 232: pack_qs<2, 32>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
   case 316: pack_qs<3, 16>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
   case 416: pack_qs<4, 16>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
   case 332: pack_qs<3, 32>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;

@@ -252,7 +252,8 @@ class Pack(C.Structure):
                 ("out", C.c_int32 * 16), ("code_row", C.c_uint32 * 16)]
 
 
-PACK_SHAPES = ((4, 1), (4, 2), (4, 4), (8, 2), (8, 4), (16, 3), (16, 4), (32, 3), (32, 4), (32, 6), (32, 8))  # (S, Q)
+PACK_SHAPES = ((4, 1), (4, 2), (4, 4), (8, 2), (8, 4), (16, 2), (16, 3), (16, 4), (32, 2), (32, 3), (32, 4), (32, 6),
+               (32, 8))  # (S, Q)
 
 
 def run_pack(em, orc, prof, S, Q, seqs, mh=True, h3=False, quant=None):

@@ -105,3 +105,34 @@ def test_many_reads_beyond_the_grid_y_limit(engine, orc):
     xt = orc.xtrans(10, True, False)
     for i, s in enumerate(pick):
         assert bits(nul[i]) == bits(orc.null(prof, xt, reads[s])) and bits(alt[i]) == bits(orc.cost(prof, xt, reads[s])), s
+
+
+def test_lrt_filter_on_the_device(engine, orc):
+    """dcp_hip_cost_hits: process_window's filter (c-core/thread.c:118-121) as a kernel -- the same windows, in
+    the same order, with the same lrt bits as filtering dcp_hip_cost's scores on the host (c-core/lrt.h:6-9)."""
+    import os
+
+    import deciphon_amd
+    from deciphon_amd import host, synth
+    from dcp_testlib import GOLDEN
+
+    engine.clear_profiles()
+    engine.load_dcp(os.path.join(GOLDEN, "minifam.dcp"))
+    rng = np.random.default_rng(21)
+    dead = synth_profile(rng, 40)
+    dead.trans[0, :] = np.float32(np.inf)  # no way into the core: viterbi_cost = +inf, lrt = -inf
+    engine.add_profile(dead.K, dead.trans, dead.match, dead.null, dead.bg)
+    engine.commit()
+    seeds = synth.load_seeds(os.path.join(GOLDEN, "minifam.dcp"))
+    reads = synth.synth_reads(300, 1500, [s["consensus"] for s in seeds], 77, planted_every=3)
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    wins = np.array([(p, s, 0, 1500) for p in range(4) for s in range(len(reads))], np.int32)
+    nul, alt = engine.cost(wins)
+    lrt = np.array([host.lrt(-a, -b) for a, b in zip(nul, alt)], np.float32)
+    keep = np.nonzero(np.isfinite(lrt) & (lrt >= 0))[0]
+    idx, got = engine.cost_hits(wins)
+    assert 50 <= len(keep) < len(wins) // 2 and not np.isfinite(lrt[3 * len(reads):]).any()
+    assert np.array_equal(idx, keep.astype(np.int32))
+    assert np.array_equal(got.view(np.uint32), lrt[keep].view(np.uint32))
+    assert engine.cost_hits(wins[:0])[0].size == 0
