@@ -66,3 +66,35 @@ struct DcpPack
   int32_t out[16];       // slot in the output arrays
   uint32_t code_row[16]; // index of the window's position 0 in the DcpCodeRow array
 };
+
+// ---- fast path pass in blocks (checkpoint + recompute) -------------------------------------------------
+// A window's DP table (12 B per cell) is never held whole.  A first pass (the cost kernel) leaves the FOLDED ring
+// of five rows -- Mpre[5][Kp], Ipre[5][Kp], Spre[5] and X per lane -- every B rows (B a multiple of 5): checkpoint j is the
+// state after row j * B.  Blocks are then taken from the last to the first: block j is recomputed from checkpoint
+// j (block 0 from row 0) over rows j*B + 1 .. min(L, (j+1)*B + 5) into a table of B + 6 rows (row l at slot
+// l - j*B), and the traceback walks the part of the path whose stage lies in (j*B + 5, (j+1)*B + 5] -- every
+// row it reads there, stage - 5 .. stage, is in the block's table -- before handing over to block j - 1.
+#ifdef __HIPCC__
+#define DCP_HDI __host__ __device__ inline
+#else
+#define DCP_HDI inline
+#endif
+#define DCP_CKPT_ROWS_DEFAULT 500
+#define DCP_CKPT_SP 6 // lane rows of specials per checkpoint: Spre[5], X
+DCP_HDI long long dcp_ckpt_floats(int Kp, int W) { return 10LL * Kp + (long long)DCP_CKPT_SP * 64 * W; } // W waves per window
+
+// blocks of a window of L rows with checkpoints every B rows (B = 0: one block, the whole window)
+DCP_HDI int dcp_num_blocks(int L, int B) { return B <= 0 || L <= B + 5 ? 1 : (L - 5 + B - 1) / B; }
+
+// rows a block's table holds, the row the block starts from included (row 0 for block 0)
+DCP_HDI int dcp_block_slots(int L, int B) { return (B <= 0 || L <= B + 5 ? L : B + 5) + 1; }
+
+// where the traceback of one window stands between blocks (all zero = not started)
+struct DcpTraceState
+{
+  int32_t state;  // state id to visit next (c-core/state.h:9-25)
+  int32_t stage;  // its DP row
+  int32_t status; // 0 = under way, 1 = finished, < 0 = DCP_TB_*
+  int32_t pad;
+  int64_t n;      // steps written so far (from the end of the step buffer backwards)
+};

@@ -66,7 +66,7 @@ template <class T> struct DevBuf
 // freeing never meets that).  place() hands out device addresses, reset() starts a new slice.
 struct TableArena
 {
-  static constexpr size_t CHUNK = (size_t)12 << 30;
+  static constexpr size_t CHUNK = (size_t)2 << 30;
   struct Chunk { unsigned char *p; size_t size, used; };
   std::vector<Chunk> chunks;
   size_t held = 0;      // bytes in all chunks
@@ -180,6 +180,8 @@ struct dcp_hip
   DevBuf<DcpPack> d_packs;         // cost pass: windows of short profiles, several per wavefront
   DevBuf<float> d_out;
   DevBuf<int64_t> d_aux;           // strip class, literal path pass: table and scratch addresses per window
+  DevBuf<int64_t> d_ckpt_addr;     // fast path pass: checkpoint address per window
+  DevBuf<DcpTraceState> d_trace;   // fast path pass: where each window's traceback stands between blocks
   DevBuf<float> d_ring;            // strip class (K > 4096): the rings of folded rows, one per workgroup in flight
   TableArena tables;               // DP tables of the fast path pass
   std::vector<int64_t> table_addr; // per window of the slice being staged (device addresses)
@@ -253,6 +255,20 @@ enum ArenaKind { ARENA_NONE, ARENA_TRELLIS, ARENA_TABLE };
 
 // DP table of one window: float specials[(L+1)][8], float cells[(L+1)][3][Kp] (traceback.h)
 size_t table_bytes(int L, int Kp) { return ((size_t)L + 1) * (DCP_SP_STRIDE + 3 * (size_t)Kp) * 4; }
+
+// The fast path pass in blocks (dcp_types.h): rows between checkpoints.  DECIPHON_HIP_CKPT_ROWS overrides (tests
+// use small blocks; 0 = whole windows, the tables of round 1); always a multiple of 5.
+int ckpt_rows()
+{
+  int B = DCP_CKPT_ROWS_DEFAULT;
+  if (char const *e = getenv("DECIPHON_HIP_CKPT_ROWS")) B = atoi(e);
+  if (B < 0) B = 0;
+  return B - B % 5;
+}
+// one block's table, then the window's checkpoints (16-byte aligned)
+size_t block_table_bytes(int L, int Kp, int B) { return (size_t)dcp_block_slots(L, B) * (DCP_SP_STRIDE + 3 * (size_t)Kp) * 4; }
+size_t ckpt_bytes(int L, int Kp, int W, int B) { return (size_t)(dcp_num_blocks(L, B) - 1) * (size_t)dcp_ckpt_floats(Kp, W) * 4; }
+size_t fast_bytes(int L, int Kp, int W, int B) { return ((block_table_bytes(L, Kp, B) + 15) & ~(size_t)15) + ckpt_bytes(L, Kp, W, B); }
 
 // validates windows and builds the device problem list
 int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Staged &st)
@@ -1203,7 +1219,7 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
       HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
       DcpLaunch a = launch_args(x, ss, DCP_STRIP_CLASS);
       a.arena = nullptr;
-      HIP_TRY(x, dcp_launch_cost_store(DCP_STRIP_CLASS, a), DCP_EFUNCUSE);
+      HIP_TRY(x, dcp_launch_cost_store(DCP_STRIP_CLASS, a, nullptr, 0, 0), DCP_EFUNCUSE);
     }
   }
   Staged st;
@@ -1310,12 +1326,40 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
   if (rc) return rc;
   tm.lap("stage");
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  int const B = ckpt_rows();
+  // checkpoints sit behind each window's block table (dcp_hip_path placed fast_bytes per window)
+  std::vector<int64_t> ckpt_addr((size_t)n, 0);
+  int max_blocks = 1;
+  bool strip = false;
+  for (DcpProblem const &p : st.problems)
   {
-    // the classes of a slice are each too small to fill the GPU and each lasts as long as its longest
-    // window: they go out on their own streams, forked from and joined back into x->stream
-    int classes = 0;
-    for (int c = 0; c < DCP_NUM_CLASSES; ++c) classes += st.c_begin[c + 1] > st.c_begin[c];
-    bool const fork = classes > 1;
+    HostProfile const &hp = x->profiles[(size_t)p.profile];
+    if (hp.cls == DCP_STRIP_CLASS) strip = true; // whole tables (dcp_hip_path placed table_bytes for them)
+    else
+    {
+      ckpt_addr[(size_t)p.out] = p.trellis + (int64_t)((block_table_bytes(p.L, hp.Kp, B) + 15) & ~(size_t)15);
+      max_blocks = std::max(max_blocks, dcp_num_blocks(p.L, B));
+    }
+  }
+  HIP_TRY(x, x->d_ckpt_addr.reserve((size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, hipMemcpyAsync(x->d_ckpt_addr.p, ckpt_addr.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, x->stream),
+          DCP_EFUNCUSE);
+  HIP_TRY(x, x->d_trace.reserve((size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, hipMemsetAsync(x->d_trace.p, 0, (size_t)n * sizeof(DcpTraceState), x->stream), DCP_EFUNCUSE);
+  std::vector<int64_t> step_off = step_offsets(x, st, n);
+  size_t const total_steps = (size_t)step_off[(size_t)n];
+  HIP_TRY(x, x->d_steps.reserve(total_steps), DCP_ENOMEM);
+  HIP_TRY(x, x->d_step_off.reserve((size_t)n + 1), DCP_ENOMEM);
+  HIP_TRY(x, x->d_nsteps.reserve((size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, hipMemcpyAsync(x->d_step_off.p, step_off.data(), ((size_t)n + 1) * sizeof(int64_t),
+                            hipMemcpyHostToDevice, x->stream),
+          DCP_EFUNCUSE);
+  // the classes of a slice are each too small to fill the GPU and each lasts as long as its longest window:
+  // they go out on their own streams, forked from and joined back into x->stream
+  int classes = 0;
+  for (int c = 0; c < DCP_NUM_CLASSES; ++c) classes += st.c_begin[c + 1] > st.c_begin[c];
+  bool const fork = classes > 1;
+  auto per_class = [&](auto &&launch) -> int {
     if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
     for (int c = 0; c < DCP_NUM_CLASSES; ++c)
     {
@@ -1327,29 +1371,41 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
         a.stream = x->qstream[c];
         HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
       }
-      HIP_TRY(x, dcp_launch_cost_store(c, a), DCP_EFUNCUSE);
+      HIP_TRY(x, launch(c, a), DCP_EFUNCUSE);
       if (fork)
       {
         HIP_TRY(x, hipEventRecord(x->join_ev[c], a.stream), DCP_EFUNCUSE);
         HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
       }
     }
-  }
-  tm.lap("cost+store");
-  std::vector<int64_t> step_off = step_offsets(x, st, n);
-  size_t const total_steps = (size_t)step_off[(size_t)n];
-  HIP_TRY(x, x->d_steps.reserve(total_steps), DCP_ENOMEM);
-  HIP_TRY(x, x->d_step_off.reserve((size_t)n + 1), DCP_ENOMEM);
-  HIP_TRY(x, x->d_nsteps.reserve((size_t)n), DCP_ENOMEM);
-  HIP_TRY(x, hipMemcpyAsync(x->d_step_off.p, step_off.data(), ((size_t)n + 1) * sizeof(int64_t),
-                            hipMemcpyHostToDevice, x->stream),
-          DCP_EFUNCUSE);
+    return 0;
+  };
+  if (max_blocks > 1) // the checkpoints of the windows that have more than one block
+    if ((rc = per_class([&](int c, DcpLaunch const &a) {
+          return c == DCP_STRIP_CLASS ? hipSuccess : dcp_launch_cost_ckpt(c, a, x->d_ckpt_addr.p, B);
+        })))
+      return rc;
+  tm.lap("checkpoints");
+  for (int block = max_blocks - 1; block >= 0; --block)
   {
-    DcpLaunch a = launch_args(x, st, 0);
-    a.problems = x->d_problems.p;
-    a.nprob = n;
-    a.arena = nullptr;
-    HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p), DCP_EFUNCUSE);
+    if ((rc = per_class([&](int c, DcpLaunch const &a) {
+          if (c == DCP_STRIP_CLASS) return block == 0 ? dcp_launch_cost_store(c, a, nullptr, 0, 0) : hipSuccess;
+          return dcp_launch_cost_store(c, a, x->d_ckpt_addr.p, B, block);
+        })))
+      return rc;
+    if (strip && block == 0) // their tables hold the whole window: one traceback call, as one block
+    {
+      DcpLaunch a = launch_args(x, st, DCP_STRIP_CLASS);
+      a.arena = nullptr;
+      HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, 0, 0), DCP_EFUNCUSE);
+    }
+    for (int c = 0; c < DCP_STRIP_CLASS; ++c)
+    {
+      DcpLaunch a = launch_args(x, st, c);
+      if (a.nprob <= 0) continue;
+      a.arena = nullptr;
+      HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, B, block), DCP_EFUNCUSE);
+    }
   }
   tm.lap("traceback");
   std::vector<float> out(2 * (size_t)n);
@@ -1385,7 +1441,9 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
 // few windows it holds, so more memory means fewer, fuller slices -- but VRAM is cleared when it
 // is allocated (35 GB/s, scripts/alloc_timing.py), so an arena sized for the whole request costs
 // more than the slices it saves unless the engine lives long.  Default: what dcp_hip_path_reserve
-// set aside, at least 24 GB.  DECIPHON_HIP_PATH_BUDGET_MB overrides.
+// set aside, at least 4 GB -- enough for thousands of windows since the tables are held a block at a time
+// (12 B per cell of 505 rows plus 40 B per position and 500 rows of checkpoints, about a fifteenth of a 10 kb
+// window's whole table).  DECIPHON_HIP_PATH_BUDGET_MB overrides.
 size_t path_budget(dcp_hip *x)
 {
   if (char const *e = getenv("DECIPHON_HIP_PATH_BUDGET_MB")) return (size_t)std::max(atol(e), 1L) << 20;
@@ -1439,6 +1497,7 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
     for (int i = 0; i < n; ++i) x->path_sorted[(size_t)i] = w[x->path_order[(size_t)i]];
     // slices bounded by the HBM their DP tables take
     size_t const budget = path_budget(x);
+    int const B = ckpt_rows();
     dcp_hip_window const *ws = x->path_sorted.data();
     for (int b = 0; b < n;)
     {
@@ -1447,8 +1506,11 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
       x->table_addr.clear();
       while (e < n)
       {
-        unsigned char *at =
-            x->tables.place(table_bytes(ws[e].stop - ws[e].start, x->profiles[(size_t)ws[e].profile].Kp), budget);
+        // one block's table and the checkpoints (dcp_types.h); the whole table beyond 4096 positions
+        HostProfile const &hp = x->profiles[(size_t)ws[e].profile];
+        int const L = ws[e].stop - ws[e].start;
+        unsigned char *at = x->tables.place(
+            hp.cls == DCP_STRIP_CLASS ? table_bytes(L, hp.Kp) : fast_bytes(L, hp.Kp, hp.W, B), budget);
         if (!at) break;
         x->table_addr.push_back((int64_t)(uintptr_t)at);
         ++e;

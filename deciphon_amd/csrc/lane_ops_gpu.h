@@ -530,6 +530,10 @@ template <int Q> DCP_FN void store_q(float *__restrict__ row, lu lane, lf const 
   }
 }
 
+// one float per lane of the group, lane-indexed
+DCP_FN void store_lane(float *__restrict__ p, lu lane, lf v) { p[lane] = v; }
+DCP_FN lf load_lane(float const *__restrict__ p, lu lane) { return p[lane]; }
+
 DCP_FN void store_sp_lane0(float *__restrict__ p, lu lane, lf N, lf B, lf J, lf E, lf C)
 {
   if (lane == 0)

@@ -238,7 +238,7 @@ int setup_common(dcp_scan *x, char const *dbfile, int device, int index, int npa
     // and the clearing then overlaps the database load and the first cost pass.  Best effort:
     // dcp_hip_path allocates what it needs anyway.
     char const *mb = getenv("DECIPHON_HIP_PATH_BUDGET_MB");
-    (void)dcp_hip_path_reserve(x->eng, mb ? (int64_t)std::max(atol(mb), 1L) << 20 : (int64_t)24 << 30);
+    (void)dcp_hip_path_reserve(x->eng, mb ? (int64_t)std::max(atol(mb), 1L) << 20 : (int64_t)4 << 30);
   }
   if (x->num_proteins > 0)
   {

@@ -35,11 +35,15 @@ struct DcpTraceIn
   float const *trans; // [8][Kp]
   DcpCodeRow const *codes; // row l = codes of the t-mers ending at window position l
   float const *xt;    // 13 special transitions
+  // blocks (dcp_types.h): the table holds rows row_base .. and the walk stops, to be resumed on the block
+  // before, at the first state whose stage is <= lo (lo < 0: never)
+  int row_base = 0, lo = -1;
 };
 
 // Writes the steps (state_id | seqsize << 16) from the END of buf backwards; returns their
-// number, or a DCP_TB_* code.
-DCP_HD int dcp_traceback(DcpTraceIn const &in, uint32_t *buf, int64_t cap)
+// number, or a DCP_TB_* code -- or 0 when the walk stopped at in.lo with where it stands in *st
+// (st != NULL: resume from *st unless it is fresh, i.e. zeroed -- no state id is 0).
+DCP_HD int dcp_traceback(DcpTraceIn const &in, uint32_t *buf, int64_t cap, DcpTraceState *st = nullptr)
 {
   enum
   {
@@ -49,16 +53,30 @@ DCP_HD int dcp_traceback(DcpTraceIn const &in, uint32_t *buf, int64_t cap)
   float const INF = __builtin_inff();
   int const K = in.K, Kp = in.Kp;
   size_t const stride = (size_t)Kp + DCP_ROW_HDR;
-  auto SP = [&](int l, int i) { return in.sp[(size_t)l * DCP_SP_STRIDE + i]; }; // 0 N, 1 B, 2 J, 3 E, 4 C
-  auto CELL = [&](int l, int s, int k) { return k < 0 ? INF : in.cells[((size_t)l * 3 + s) * (size_t)Kp + k]; };
+  int const base = in.row_base;
+  auto SP = [&](int l, int i) { return in.sp[(size_t)(l - base) * DCP_SP_STRIDE + i]; }; // 0 N, 1 B, 2 J, 3 E, 4 C
+  auto CELL = [&](int l, int s, int k) { return k < 0 ? INF : in.cells[((size_t)(l - base) * 3 + s) * (size_t)Kp + k]; };
   auto ROW = [&](int l, int t) { return in.rows + (size_t)in.codes[l].c[t - 1] * stride; };
   auto TR = [&](int id, int k) { return in.trans[(size_t)id * Kp + k]; };
   float const *xt = in.xt;
 
   int state = ST_T, stage = in.L;
   int64_t n = 0;
+  if (st && st->state != 0)
+  {
+    state = st->state;
+    stage = st->stage;
+    n = st->n;
+  }
   while (state != ST_S || stage)
   {
+    if (stage <= in.lo)
+    {
+      st->state = state;
+      st->stage = stage;
+      st->n = n;
+      return 0;
+    }
     int size = 0, prev = -1;
     if ((state & ST_X) == ST_X)
     {

@@ -62,6 +62,36 @@ template <int Q, int W, bool STORE = false> struct CostWave
   float *__restrict__ tab_cells = nullptr; // [(L+1)][3][Kp]
   float *__restrict__ tab_sp = nullptr;    // [(L+1)][DCP_SP_STRIDE]
   int tabKp = 0;
+  // blocks (dcp_types.h, "fast path pass in blocks"): ckpt_every > 0 saves the folded ring after every
+  // ckpt_every-th row into ckpt_out; ckpt_in resumes from a saved ring at row row_base, and rows are stored at
+  // table slot l - row_base
+  float *__restrict__ ckpt_out = nullptr;
+  float const *__restrict__ ckpt_in = nullptr;
+  int ckpt_every = 0;
+  int row_base = 0;
+
+  DCP_FN void save_ring(float *__restrict__ to)
+  {
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+    {
+      store_q<Q>(to + (size_t)s * tabKp, g.lane, Mpre[s]);
+      store_q<Q>(to + (size_t)(5 + s) * tabKp, g.lane, Ipre[s]);
+      store_lane(to + (size_t)10 * tabKp + s * 64 * W, g.lane, Spre[s]);
+    }
+    store_lane(to + (size_t)10 * tabKp + 5 * 64 * W, g.lane, X);
+  }
+  DCP_FN void load_ring(float const *__restrict__ from)
+  {
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+    {
+      load_q<Q>(from + (size_t)s * tabKp, g.lane, Mpre[s]);
+      load_q<Q>(from + (size_t)(5 + s) * tabKp, g.lane, Ipre[s]);
+      Spre[s] = load_lane(from + (size_t)10 * tabKp + s * 64 * W, g.lane);
+    }
+    X = load_lane(from + (size_t)10 * tabKp + 5 * 64 * W, g.lane);
+  }
   lf BM[Q], MM[Q], MI[Q], MD[Q], IM[Q], II[Q], DM[Q], DD[Q];
   lf Mpre[5][Q], Ipre[5][Q], Spre[5];
   lf em[5][Q];
@@ -162,7 +192,10 @@ template <int Q, int W, bool STORE = false> struct CostWave
     X = lsel(l3, lf_splat(-RR), inf);
     E = DCP_INF;
     tabKp = Kp;
-    if (STORE) store_row0(SB);
+    if (ckpt_in)
+      load_ring(ckpt_in); // a block that starts at row row_base > 0
+    else if (STORE)
+      store_row0(SB);
   }
 
   template <int P> DCP_FN void row(int l, int L)
@@ -348,12 +381,13 @@ template <int Q, int W, bool STORE = false> struct CostWave
     Spre[P] = lmin(lf_splat(E) + sa, X + sb);
     if (STORE)
     {
-      float *row = tab_cells + (size_t)l * 3 * (size_t)tabKp;
+      float *row = tab_cells + (size_t)(l - row_base) * 3 * (size_t)tabKp;
       store_q<Q>(row, g.lane, M);
       store_q<Q>(row + tabKp, g.lane, I);
       store_q<Q>(row + 2 * tabKp, g.lane, D);
       float const C = g.get_lane(GS_X0 + (l & 1), X, 2);
-      store_sp_lane0(tab_sp + (size_t)l * DCP_SP_STRIDE, g.lane, lf_splat(N), B, lf_splat(J), lf_splat(E), lf_splat(C));
+      store_sp_lane0(tab_sp + (size_t)(l - row_base) * DCP_SP_STRIDE, g.lane, lf_splat(N), B, lf_splat(J), lf_splat(E),
+                     lf_splat(C));
     }
   }
 
@@ -370,27 +404,31 @@ template <int Q, int W, bool STORE = false> struct CostWave
     store_sp_lane0(tab_sp, g.lane, i, lf_splat(SB), i, i, i);
   }
 
-  // out[0] = viterbi_null(), out[1] = viterbi_cost()
-  DCP_FN void run(int L, float *out)
+  // out[0] = viterbi_null(), out[1] = viterbi_cost().  Lend < L: stop after row Lend (a block; out untouched).
+  DCP_FN void run(int L, float *out, int Lend = -1)
   {
-    if (L > 0)
+    if (Lend < 0 || Lend > L) Lend = L;
+    int l = row_base + 1; // row_base is a multiple of 5: the block starts in phase 1 like row 1
+    if (l <= Lend)
     {
-      cr = codes[1];
-      fetch(2, L);
+      cr = codes[l];
+      fetch(l + 1, Lend);
     }
-    int l = 1;
-    for (; l + 4 <= L; l += 5)
+    for (; l + 4 <= Lend; l += 5)
     {
-      row<1>(l, L);
-      row<2>(l + 1, L);
-      row<3>(l + 2, L);
-      row<4>(l + 3, L);
-      row<0>(l + 4, L);
+      row<1>(l, Lend);
+      row<2>(l + 1, Lend);
+      row<3>(l + 2, Lend);
+      row<4>(l + 3, Lend);
+      row<0>(l + 4, Lend);
+      if (ckpt_every > 0 && (l + 4) % ckpt_every == 0 && l + 4 + 5 < L) // checkpoint j exists iff j * B < L - 5
+        save_ring(ckpt_out + (size_t)((l + 4) / ckpt_every - 1) * (size_t)dcp_ckpt_floats(tabKp, W));
     }
-    if (l <= L) row<1>(l++, L);
-    if (l <= L) row<2>(l++, L);
-    if (l <= L) row<3>(l++, L);
-    if (l <= L) row<4>(l++, L);
+    if (l <= Lend) row<1>(l++, Lend);
+    if (l <= Lend) row<2>(l++, Lend);
+    if (l <= Lend) row<3>(l++, Lend);
+    if (l <= Lend) row<4>(l++, Lend);
+    if (Lend < L) return;
     g.sync();
     g.put_lanes4(GS_X, X);
     g.sync();

@@ -47,8 +47,11 @@ hipError_t dcp_launch_path(int cls, DcpLaunch const &a);
 hipError_t dcp_launch_unzip(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps);
 // fast path pass: cost pass that stores each window's DP table at arena + problem.trellis, then the
 // traceback of every problem of a.problems (all classes) into steps / nsteps (as dcp_launch_unzip)
-hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a);
-hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps);
+// (in blocks, dcp_types.h: B rows between checkpoints, 0 = whole windows; ckpt_addr[out] = the window's checkpoints)
+hipError_t dcp_launch_cost_ckpt(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B);
+hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block);
+hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps,
+                                DcpTraceState *states, int B, int block);
 // strip class: the trellis replayed row by row from the DP tables at table_addr[out] (scratch: 3*K floats per row)
 hipError_t dcp_launch_replay(DcpLaunch const &a, int64_t const *table_addr, int64_t const *scratch_addr, int max_rows);
 hipError_t dcp_launch_compact_steps(uint32_t const *steps, int64_t const *step_off, int64_t const *compact_off,

@@ -49,8 +49,32 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_kernel(floa
   w.run(pb.L, out + 2 * (size_t)pb.out);
 }
 
-// Fast path pass, step 1: the cost pass that also leaves the DP table of its window in the
-// arena: float specials[(L+1)][8] followed by float cells[(L+1)][3][Kp].
+// Fast path pass in blocks (dcp_types.h).  First the checkpoints: the cost pass once more over the hit windows,
+// leaving the folded ring of five rows every B rows (windows of a single block need none and leave at once).
+template <int Q, int W>
+__global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_ckpt_kernel(float const *__restrict__ pool,
+                                                           DcpProfileDev const *__restrict__ profiles,
+                                                           DcpProblem const *__restrict__ problems,
+                                                           DcpCodeRow const *__restrict__ code_rows,
+                                                           float const *__restrict__ xt_table,
+                                                           int64_t const *__restrict__ ckpt_addr, int B,
+                                                           float *__restrict__ out, int nprob)
+{
+  if ((int)blockIdx.x >= nprob) return;
+  DcpProblem const pb = problems[dcp_xcd_remap((int)blockIdx.x, nprob)];
+  if (dcp_num_blocks(pb.L, B) <= 1) return;
+  DcpProfileDev const pf = profiles[pb.profile];
+  CostWave<Q, W> w;
+  w.ckpt_out = reinterpret_cast<float *>((uintptr_t)ckpt_addr[pb.out]);
+  w.ckpt_every = B;
+  w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
+  w.run(pb.L, out + 2 * (size_t)pb.out);
+}
+
+// Then, block by block from the last to the first: the rows of block `block` of every window that has one,
+// recomputed from its checkpoint into the window's table -- float specials[slots][8] followed by float
+// cells[slots][3][Kp], slots = rows of a block + 1, row l at slot l - block * B.  B = 0: the whole window is one
+// block and the table holds all its rows (what the trellis replay of the strip class reads).
 template <int Q, int W>
 __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_store_kernel(float const *__restrict__ pool,
                                                             DcpProfileDev const *__restrict__ profiles,
@@ -58,18 +82,25 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_store_kerne
                                                             DcpCodeRow const *__restrict__ code_rows,
                                                             float const *__restrict__ xt_table,
                                                             unsigned char *__restrict__ arena,
+                                                            int64_t const *__restrict__ ckpt_addr, int B, int block,
                                                             float *__restrict__ out, int nprob)
 {
   if ((int)blockIdx.x >= nprob) return;
   int const p = dcp_xcd_remap((int)blockIdx.x, nprob);
   DcpProblem const pb = problems[p];
+  if (block >= dcp_num_blocks(pb.L, B)) return;
   DcpProfileDev const pf = profiles[pb.profile];
   CostWave<Q, W, true> w;
+  int const slots = dcp_block_slots(pb.L, B);
   // integer arithmetic: the engine passes arena = 0 and absolute table addresses in pb.trellis
   w.tab_sp = reinterpret_cast<float *>((uintptr_t)arena + (uintptr_t)pb.trellis);
-  w.tab_cells = w.tab_sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
+  w.tab_cells = w.tab_sp + (size_t)slots * DCP_SP_STRIDE;
+  w.row_base = block * B;
+  if (block > 0)
+    w.ckpt_in = reinterpret_cast<float const *>((uintptr_t)ckpt_addr[pb.out]) + (size_t)(block - 1) * (size_t)dcp_ckpt_floats(pf.Kp, W);
   w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
-  w.run(pb.L, out + 2 * (size_t)pb.out);
+  int const last = B > 0 ? (block + 1) * B + 5 : pb.L;
+  w.run(pb.L, out + 2 * (size_t)pb.out, last < pb.L ? last : pb.L);
 }
 
 // Profiles beyond 4096 positions: one workgroup walks each row strip by strip (StripWave).
@@ -162,7 +193,7 @@ hipError_t dcp_launch_replay(DcpLaunch const &a, int64_t const *table_addr, int6
 // over the lanes in the reference's order -- lane j = (5 - t) * names + name -- so that
 // one step costs two load round trips instead of a chain of them, and the first
 // candidate equal to the stored value is the lowest set bit of a ballot.
-__device__ int dcp_traceback_wave(DcpTraceIn const &in, uint32_t *buf, int64_t cap)
+__device__ int dcp_traceback_wave(DcpTraceIn const &in, uint32_t *buf, int64_t cap, DcpTraceState *st)
 {
   enum
   {
@@ -173,15 +204,32 @@ __device__ int dcp_traceback_wave(DcpTraceIn const &in, uint32_t *buf, int64_t c
   int const lane = (int)(threadIdx.x & 63);
   int const K = in.K, Kp = in.Kp;
   size_t const stride = (size_t)Kp + DCP_ROW_HDR;
-  auto SP = [&](int l, int i) { return in.sp[(size_t)l * DCP_SP_STRIDE + i]; };
-  auto CELL = [&](int l, int s, int k) { return k < 0 ? INF : in.cells[((size_t)l * 3 + s) * (size_t)Kp + k]; };
+  int const base = in.row_base;
+  auto SP = [&](int l, int i) { return in.sp[(size_t)(l - base) * DCP_SP_STRIDE + i]; };
+  auto CELL = [&](int l, int s, int k) { return k < 0 ? INF : in.cells[((size_t)(l - base) * 3 + s) * (size_t)Kp + k]; };
   auto TR = [&](int id, int k) { return in.trans[(size_t)id * Kp + k]; };
   float const *xt = in.xt;
 
   int state = ST_T, stage = in.L;
   int64_t n = 0;
+  if (st && st->state != 0) // resume where the block after this one stopped (uniform: every lane reads the same)
+  {
+    state = st->state;
+    stage = st->stage;
+    n = st->n;
+  }
   while (state != ST_S || stage)
   {
+    if (stage <= in.lo) // the rest of the path lies in the block before this one
+    {
+      if (lane == 0)
+      {
+        st->state = state;
+        st->stage = stage;
+        st->n = n;
+      }
+      return 0;
+    }
     int size = 0, prev = -1;
     DcpCodeRow const cr = in.codes[stage];
     if ((state & ST_X) == ST_X)
@@ -326,24 +374,33 @@ __global__ __launch_bounds__(64) void dcp_traceback_kernel(
     float const *__restrict__ pool, DcpProfileDev const *__restrict__ profiles, DcpProblem const *__restrict__ problems,
     DcpCodeRow const *__restrict__ code_rows, float const *__restrict__ xt_table,
     unsigned char const *__restrict__ arena, uint32_t *__restrict__ steps, int64_t const *__restrict__ step_off,
-    int32_t *__restrict__ nsteps, int nprob)
+    int32_t *__restrict__ nsteps, DcpTraceState *__restrict__ states, int B, int block, int nprob)
 {
   int const p = (int)blockIdx.x;
   if (p >= nprob) return;
   DcpProblem const pb = problems[p];
+  if (block >= dcp_num_blocks(pb.L, B)) return;
+  DcpTraceState *st = states + pb.out;
+  if (st->status != 0) return; // finished, or given up, in a later block
   DcpProfileDev const pf = profiles[pb.profile];
   DcpTraceIn in;
   in.K = pf.K;
   in.Kp = pf.Kp;
   in.L = pb.L;
   in.sp = reinterpret_cast<float const *>((uintptr_t)arena + (uintptr_t)pb.trellis);
-  in.cells = in.sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
+  in.cells = in.sp + (size_t)dcp_block_slots(pb.L, B) * DCP_SP_STRIDE;
   in.rows = pool + pf.rows_off;
   in.trans = pool + pf.trans_off;
   in.codes = code_rows + pb.code_row;
   in.xt = xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE;
-  int const r = dcp_traceback_wave(in, steps + step_off[pb.out], step_off[pb.out + 1] - step_off[pb.out]);
-  if ((threadIdx.x & 63) == 0) nsteps[pb.out] = r;
+  in.row_base = block * B;
+  in.lo = block > 0 ? block * B + 5 : -1;
+  int const r = dcp_traceback_wave(in, steps + step_off[pb.out], step_off[pb.out + 1] - step_off[pb.out], st);
+  if ((threadIdx.x & 63) == 0 && r != 0)
+  {
+    st->status = r > 0 ? 1 : r;
+    nsteps[pb.out] = r;
+  }
 }
 
 // All single-wave classes in one launch: small scans (a few thousand windows spread
@@ -675,39 +732,67 @@ hipError_t dcp_launch_cost(int cls, DcpLaunch const &a)
   }
 }
 
-template <int Q, int W> static hipError_t launch_store_qw(DcpLaunch const &a)
+template <int Q, int W> static hipError_t launch_store_qw(DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block)
 {
   hipLaunchKernelGGL((dcp_cost_store_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool,
-                     a.profiles, a.problems, a.code_rows, a.xt_table, a.arena, a.out, a.nprob);
+                     a.profiles, a.problems, a.code_rows, a.xt_table, a.arena, ckpt_addr, B, block, a.out, a.nprob);
   return hipGetLastError();
 }
 
-hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a)
+hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block)
 {
   if (a.nprob <= 0) return hipSuccess;
   switch (cls)
   {
-  case 0: return launch_store_qw<1, 1>(a);
-  case 1: return launch_store_qw<2, 1>(a);
-  case 2: return launch_store_qw<3, 1>(a);
-  case 3: return launch_store_qw<4, 1>(a);
-  case 4: return launch_store_qw<6, 1>(a);
-  case 5: return launch_store_qw<8, 1>(a);
-  case 6: return launch_store_qw<6, 2>(a);
-  case 7: return launch_store_qw<4, 4>(a);
-  case 8: return launch_store_qw<6, 4>(a);
-  case 9: return launch_store_qw<8, 4>(a);
-  case 10: return launch_store_qw<8, 8>(a);
-  case DCP_STRIP_CLASS: return launch_strip<true>(a);
+  case 0: return launch_store_qw<1, 1>(a, ckpt_addr, B, block);
+  case 1: return launch_store_qw<2, 1>(a, ckpt_addr, B, block);
+  case 2: return launch_store_qw<3, 1>(a, ckpt_addr, B, block);
+  case 3: return launch_store_qw<4, 1>(a, ckpt_addr, B, block);
+  case 4: return launch_store_qw<6, 1>(a, ckpt_addr, B, block);
+  case 5: return launch_store_qw<8, 1>(a, ckpt_addr, B, block);
+  case 6: return launch_store_qw<6, 2>(a, ckpt_addr, B, block);
+  case 7: return launch_store_qw<4, 4>(a, ckpt_addr, B, block);
+  case 8: return launch_store_qw<6, 4>(a, ckpt_addr, B, block);
+  case 9: return launch_store_qw<8, 4>(a, ckpt_addr, B, block);
+  case 10: return launch_store_qw<8, 8>(a, ckpt_addr, B, block);
+  case DCP_STRIP_CLASS: return B == 0 && block == 0 ? launch_strip<true>(a) : hipErrorInvalidValue; // whole tables only
   default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps)
+template <int Q, int W> static hipError_t launch_ckpt_qw(DcpLaunch const &a, int64_t const *ckpt_addr, int B)
+{
+  hipLaunchKernelGGL((dcp_cost_ckpt_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool, a.profiles,
+                     a.problems, a.code_rows, a.xt_table, ckpt_addr, B, a.out, a.nprob);
+  return hipGetLastError();
+}
+
+hipError_t dcp_launch_cost_ckpt(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B)
+{
+  if (a.nprob <= 0) return hipSuccess;
+  switch (cls)
+  {
+  case 0: return launch_ckpt_qw<1, 1>(a, ckpt_addr, B);
+  case 1: return launch_ckpt_qw<2, 1>(a, ckpt_addr, B);
+  case 2: return launch_ckpt_qw<3, 1>(a, ckpt_addr, B);
+  case 3: return launch_ckpt_qw<4, 1>(a, ckpt_addr, B);
+  case 4: return launch_ckpt_qw<6, 1>(a, ckpt_addr, B);
+  case 5: return launch_ckpt_qw<8, 1>(a, ckpt_addr, B);
+  case 6: return launch_ckpt_qw<6, 2>(a, ckpt_addr, B);
+  case 7: return launch_ckpt_qw<4, 4>(a, ckpt_addr, B);
+  case 8: return launch_ckpt_qw<6, 4>(a, ckpt_addr, B);
+  case 9: return launch_ckpt_qw<8, 4>(a, ckpt_addr, B);
+  case 10: return launch_ckpt_qw<8, 8>(a, ckpt_addr, B);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps,
+                                DcpTraceState *states, int B, int block)
 {
   if (a.nprob <= 0) return hipSuccess;
   hipLaunchKernelGGL(dcp_traceback_kernel, dim3((unsigned)a.nprob), dim3(64), 0, a.stream, a.pool, a.profiles, a.problems,
-                     a.code_rows, a.xt_table, a.arena, steps, step_off, nsteps, a.nprob);
+                     a.code_rows, a.xt_table, a.arena, steps, step_off, nsteps, states, B, block, a.nprob);
   return hipGetLastError();
 }
 

@@ -233,6 +233,8 @@ template <int Q> inline void store_q(float *row, lu lane, lf const (&v)[Q])
 {
   for (int q = 0; q < Q; ++q) EM_FOR row[lane.v[i_] * Q + q] = v[q].v[i_];
 }
+inline void store_lane(float *p, lu lane, lf v) { EM_FOR p[lane.v[i_]] = v.v[i_]; }
+inline lf load_lane(float const *p, lu lane) { lf r; EM_FOR r.v[i_] = p[lane.v[i_]]; return r; }
 inline void store_sp_lane0(float *p, lu, lf N, lf B, lf J, lf E, lf C)
 {
   p[0] = N.v[0]; p[1] = B.v[0]; p[2] = J.v[0]; p[3] = E.v[0]; p[4] = C.v[0];

@@ -324,3 +324,44 @@ def test_packed_windows_with_long_delete_runs(em, orc):
         for g, s in enumerate(seqs):
             x = np.ascontiguousarray(xt[max(len(s) // 3, 1), :13])
             assert bits(out[g, 0]) == bits(orc.null(prof, x, s)) and bits(out[g, 1]) == bits(orc.cost(prof, x, s)), (S, Q, g)
+
+
+def test_fast_path_pass_in_blocks(em, orc):
+    """The DP table a block at a time (dcp_types.h): checkpoints of the folded ring every B rows, every block
+    recomputed from its checkpoint into a table of B + 6 rows (never-written slots hold NaN), the traceback
+    resumed from block to block -- the same steps as trellis_unzip on the oracle's trellis, for windows of one
+    to a dozen blocks, block boundaries in and beside insert, delete and special-state runs."""
+    em.emul_path_blocks.restype = C.c_int
+    rng = np.random.default_rng(41)
+    multi = ties = 0
+    for it in range(160):
+        K = int(rng.choice([3, 17, 64, 65, 100, 173, 241, 256, 300, 400, 600, 1000]))
+        prof = synth_profile(rng, K, None, [0, 0.05][it % 2])
+        if it % 4 == 0:  # long delete runs
+            prof.trans[7, 1:] = np.float32(0.01)
+            prof.trans[3, 1:] = np.float32(0.02)
+        B = [5, 10, 15, 20, 0][it % 5]
+        L = int(rng.integers(1, 70))
+        seq = random_seq(rng, L)
+        xt = orc.xtrans(max(L // 3, 1), it % 2, (it // 2) % 2)
+        pool, pd = pack_profile(prof)
+        rows = code_rows(seq)
+        xt16 = np.zeros(16, np.float32)
+        xt16[:13] = xt
+        cap = 2 * L + 2 * K + 64
+        buf = np.zeros(cap, np.uint32)
+        score = C.c_float(0)
+        n = em.emul_path_blocks(_vp(pool), C.byref(pd), _vp(rows), L, _vp(xt16), B, _vp(buf), C.c_long(cap), C.byref(score))
+        s_o, xo, no = orc.path(prof, xt, seq)
+        assert bits(score.value) == bits(s_o), (it, K, L, B)
+        if not np.isfinite(s_o):
+            continue
+        if n == -2:  # an exact tie the values cannot resolve (the literal pass takes over): rare with these tables
+            ties += 1
+            continue
+        assert n > 0, (it, K, L, B, n)
+        ids, sizes = orc.unzip(K, L, xo, no)
+        w = buf[cap - n:]
+        assert np.array_equal(w & 0xFFFF, ids.astype(np.uint32)) and np.array_equal(w >> 16, sizes.astype(np.uint32)), (it, K, L, B)
+        multi += B > 0 and L > B + 5
+    assert multi > 60 and ties < 8

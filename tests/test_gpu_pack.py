@@ -136,3 +136,49 @@ def test_lrt_filter_on_the_device(engine, orc):
     assert np.array_equal(idx, keep.astype(np.int32))
     assert np.array_equal(got.view(np.uint32), lrt[keep].view(np.uint32))
     assert engine.cost_hits(wins[:0])[0].size == 0
+
+
+@pytest.mark.parametrize("rows", ["50", "500", "0"])
+def test_fast_path_pass_in_blocks(engine, orc, monkeypatch, rows):
+    """The fast path pass holds a window's DP table a block at a time (checkpoints of the folded ring every
+    B rows, blocks recomputed from the last to the first, the traceback resumed from block to block): the
+    same steps as the oracle's trellis_unzip with B = 50 (dozens of blocks), the default 500 and 0 (whole
+    tables), for every single-wave and multi-wave class, on windows with planted error-bearing domains."""
+    import os
+
+    from dcp_testlib import GOLDEN
+    from deciphon_amd import synth
+    from oracle.dcp_reader import Protein
+
+    monkeypatch.setenv("DECIPHON_HIP_CKPT_ROWS", rows)
+    seeds = synth.load_seeds(os.path.join(GOLDEN, "minifam.dcp"))
+    Ks = (40, 100, 173, 250, 300, 500, 700, 1000, 1500)
+    prots = [synth.tile_protein(seeds, K, 11 * i, f"T{K}") for i, K in enumerate(Ks)]
+    engine.clear_profiles()
+    for p in prots:
+        engine.add_protein(p["core_size"], p["trans"], p["emission"], p["BMk"], p["null_emission"], p["bg_emission"])
+    engine.commit()
+    rng = np.random.default_rng(int(rows) + 3)
+    reads = []
+    for p in prots:
+        x = rng.integers(0, 4, size=1700).astype(np.uint8)
+        for at in (100, 900):
+            a = int(rng.integers(0, max(len(p["consensus"]) - 150, 1)))
+            dom = synth.mutate(synth.back_translate(p["consensus"][a : a + 150]), rng, 0.06, 0.02, 0.02)
+            x[at : at + len(dom)] = dom
+        reads.append(x)
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    wins = [(i, i, 0, 1700) for i in range(len(prots))] + [(i, i, 37, 37 + 555) for i in range(len(prots))]
+    res = engine.path(wins, trellis=False)
+    assert engine.path_redone == 0
+    for (pi, si, a, b), r in zip(wins, res):
+        p = prots[pi]
+        prof = orc.setup_profile(Protein(p["accession"], 1, p["consensus"], p["core_size"], p["null_emission"],
+                                         p["bg_emission"], p["trans"], p["emission"], p["BMk"]))
+        seq = np.ascontiguousarray(reads[si][a:b])
+        xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+        score, xo, no = orc.path(prof, xt, seq)
+        ids, sizes = orc.unzip(prof.K, len(seq), xo, no)
+        assert bits(r["score"]) == bits(score), (rows, p["core_size"], a, b)
+        assert np.array_equal(r["state_ids"], ids) and np.array_equal(r["seqsizes"], sizes), (rows, p["core_size"], a, b)
