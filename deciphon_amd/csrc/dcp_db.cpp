@@ -1,5 +1,6 @@
 // dcp_db.cpp -- see dcp_db.h
 #include "dcp_db.h"
+#include <math.h>
 #include "dcp_errors.h"
 #include "dcp_types.h"
 
@@ -368,6 +369,20 @@ static bool read_nuclt_dist(Cur &c, float *nucltp, float *codonm)
   return read_f32array(c, 4, nucltp) && read_f32array(c, 125, codonm);
 }
 
+void DcpDecoder::prepare()
+{
+  size_t const n = nucltp.size() / 4;
+  base.resize(n * 4);
+  prior.resize(n * 64);
+  memo.reset(new std::atomic<uint8_t>[n * DCP_TABLE_SIZE]);
+  for (size_t i = 0; i < n * DCP_TABLE_SIZE; ++i) memo[i].store(0xFF, std::memory_order_relaxed);
+  for (size_t i = 0; i < n * 4; ++i) base[i] = exp((double)nucltp[i]);
+  for (size_t e = 0; e < n; ++e)
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 4; ++b)
+        for (int c = 0; c < 4; ++c) prior[e * 64 + (size_t)(a * 16 + b * 4 + c)] = exp((double)codonm[e * 125 + (size_t)(a * 25 + b * 5 + c)]);
+}
+
 int DcpDbReader::read_decoder(int i, DcpDecoder &x) const
 {
   if (!data_ || i < 0 || i >= num_proteins()) return DCP_EINVALPART;
@@ -399,7 +414,9 @@ int DcpDbReader::read_decoder(int i, DcpDecoder &x) const
     if (!expect_key(c, "trans") || !skip(c)) return DCP_EFDATA;
     if (!expect_key(c, "emission") || !skip(c)) return DCP_EFDATA;
   }
-  return c.ok ? 0 : DCP_EFDATA;
+  if (!c.ok) return DCP_EFDATA;
+  x.prepare();
+  return 0;
 }
 
 int DcpDbReader::read_protein_head(int i, int &core_size, std::string &accession) const

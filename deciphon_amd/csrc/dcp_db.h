@@ -10,6 +10,8 @@
 // writer, c-core/write.c:59-66) and the legacy big-endian `ext` types 8 / 6 of
 // the committed fixture control/tests/files/minifam.dcp.
 #pragma once
+#include <atomic>
+#include <memory>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -38,6 +40,14 @@ struct DcpDecoder
   // [K + 3]: 0 = null, 1 = background, 2 + n = node n (n = 0..K)
   std::vector<float> nucltp; // [(K + 3) * 4]
   std::vector<float> codonm; // [(K + 3) * 125]
+  // probabilities of the above, made once when the distributions are read (decoding runs once per path step):
+  std::vector<double> base;  // [(K + 3) * 4]  exp(nucltp)
+  std::vector<double> prior; // [(K + 3) * 64] exp(codonm) of the 64 codons, index a * 16 + b * 4 + c
+  // decoded codon (a * 16 + b * 4 + c) by [entry][quasi-codon code 0..1363], filled as steps ask for them:
+  // 0xFF = not decoded yet, 0xFE = no codon has positive probability.  A scan decodes the same few codes of
+  // the same nodes over and over.
+  std::unique_ptr<std::atomic<uint8_t>[]> memo;
+  void prepare();
 };
 
 struct DcpDbHeader

@@ -418,20 +418,38 @@ double frag_given_codon(double e, double const p[4], uint8_t const x[3], uint8_t
 
 } // namespace
 
-bool dcp_decode_codon(float epsilon, float const nucltp[4], float const codonm[125], uint8_t const *z, int n,
-                      uint8_t codon[3])
+bool dcp_decode_codon_prob(double epsilon, double const p[4], double const prior[64], uint8_t const *z, int n,
+                           uint8_t codon[3])
 {
   if (n < 1 || n > 5) return false;
-  double p[4];
-  for (int i = 0; i < 4; ++i) p[i] = exp((double)nucltp[i]);
+  if (n == 3)
+  {
+    // The common step is an exact codon.  Any other codon x reaches z only through an indel pair or two, so
+    // P(x) P(z | x) <= max P * (4 e^2 (1-e)^2 / 9 * 3 (p(z1) + p(z2) + p(z3)) + e^4 p(z1) p(z2) p(z3)): when
+    // P(z) (1-e)^4 alone exceeds that bound, z is the strict maximum and the 64-codon search is not needed.
+    double const e = epsilon, f = 1.0 - e;
+    double pmax = 0.0;
+    for (int i = 0; i < 64; ++i) pmax = prior[i] > pmax ? prior[i] : pmax;
+    double const self = prior[z[0] * 16 + z[1] * 4 + z[2]] * (f * f * f * f);
+    double const others = pmax * (4.0 * e * e * f * f / 9.0 * 3.0 * (p[z[0]] + p[z[1]] + p[z[2]]) + e * e * e * e * p[z[0]] * p[z[1]] * p[z[2]]);
+    if (self > others * (1.0 + 1e-9))
+    {
+      codon[0] = z[0];
+      codon[1] = z[1];
+      codon[2] = z[2];
+      return true;
+    }
+  }
   double best = 0.0;
   bool found = false;
   for (uint8_t a = 0; a < 4; ++a)
     for (uint8_t b = 0; b < 4; ++b)
       for (uint8_t c = 0; c < 4; ++c)
       {
+        double const px = prior[a * 16 + b * 4 + c];
+        if (!(px > 0.0)) continue;
         uint8_t const x[3] = {a, b, c};
-        double const joint = exp((double)codonm[a * 25 + b * 5 + c]) * frag_given_codon((double)epsilon, p, x, z, n);
+        double const joint = px * frag_given_codon(epsilon, p, x, z, n);
         if (joint > best)
         {
           best = joint;
@@ -442,6 +460,17 @@ bool dcp_decode_codon(float epsilon, float const nucltp[4], float const codonm[1
         }
       }
   return found;
+}
+
+bool dcp_decode_codon(float epsilon, float const nucltp[4], float const codonm[125], uint8_t const *z, int n,
+                      uint8_t codon[3])
+{
+  double p[4], prior[64];
+  for (int i = 0; i < 4; ++i) p[i] = exp((double)nucltp[i]);
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b)
+      for (int c = 0; c < 4; ++c) prior[a * 16 + b * 4 + c] = exp((double)codonm[a * 25 + b * 5 + c]);
+  return dcp_decode_codon_prob((double)epsilon, p, prior, z, n, codon);
 }
 
 char dcp_gencode_amino(int id, uint8_t const codon[3])

@@ -78,5 +78,8 @@ void dcp_partition_bounds(int n, int32_t const *core_sizes, int nparts, bool bal
 // z: nucleotide indices 0..3, n = 1..5.  Returns false when no codon has positive probability.
 bool dcp_decode_codon(float epsilon, float const nucltp[4], float const codonm[125], uint8_t const *z, int n,
                       uint8_t codon[3]);
+// the same from probabilities made once: base[4] = exp(nucltp), prior[64] = exp(codonm) of the 64 codons
+bool dcp_decode_codon_prob(double epsilon, double const base[4], double const prior[64], uint8_t const *z, int n,
+                           uint8_t codon[3]);
 // imm_gencode_decode: amino acid of a codon under NCBI translation table `gencode_id`; 0 when the table is unknown
 char dcp_gencode_amino(int gencode_id, uint8_t const codon[3]);

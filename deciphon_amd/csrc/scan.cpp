@@ -160,10 +160,27 @@ std::string format_row(dcp_batch::Seq const &seq, int window, int wstart, int ws
       int const kind = id >> 14, k = (id & 0x3FFF) - 1;
       size_t const entry = kind == 1 ? 1 : kind == 0 ? 2 + (size_t)k : 0;
       uint8_t codon[3] = {0, 0, 0};
-      bool const ok = kind <= 1 && (k < 0 || k > dec.core_size)
-                          ? false
-                          : dcp_decode_codon(dec.epsilon, dec.nucltp.data() + 4 * entry, dec.codonm.data() + 125 * entry,
-                                             seq.nt.data() + wstart + pos, n, codon);
+      bool ok = !(kind <= 1 && (k < 0 || k > dec.core_size)) && n >= 1 && n <= 5;
+      if (ok)
+      {
+        // the code of the n-mer (imm_eseq's indexing: SURVEY 8a row S) keys the decoder's memo
+        static unsigned const code_off[6] = {0, 0, 4, 20, 84, 340};
+        unsigned code = 0;
+        for (int t = 0; t < n; ++t) code = code * 4 + seq.nt[(size_t)(wstart + pos + t)];
+        std::atomic<uint8_t> &slot = dec.memo[entry * DCP_TABLE_SIZE + code_off[n] + code];
+        uint8_t m = slot.load(std::memory_order_relaxed);
+        if (m == 0xFF)
+        {
+          bool const found = dcp_decode_codon_prob((double)dec.epsilon, dec.base.data() + 4 * entry, dec.prior.data() + 64 * entry,
+                                                   seq.nt.data() + wstart + pos, n, codon);
+          m = found ? (uint8_t)(codon[0] * 16 + codon[1] * 4 + codon[2]) : (uint8_t)0xFE;
+          slot.store(m, std::memory_order_relaxed);
+        }
+        ok = m != 0xFE;
+        codon[0] = (uint8_t)(m >> 4);
+        codon[1] = (uint8_t)((m >> 2) & 3);
+        codon[2] = (uint8_t)(m & 3);
+      }
       char const amino = ok ? dcp_gencode_amino(dec.gencode, codon) : 0;
       if (!ok || !amino)
       {
