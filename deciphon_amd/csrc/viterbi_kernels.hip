@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_kernel(floa
                                                       float *__restrict__ out, int nprob)
 {
   if ((int)blockIdx.x >= nprob) return;
-#ifdef DCP_EXP_LDSPAD // timing experiment only: LDS nobody uses, to hold the wavefronts per SIMD down
+#ifdef DCP_EXP_LDSPAD // timing experiment (profiles/r02_exp_*): LDS nobody uses holds the wavefronts per SIMD down
   __shared__ float pad[DCP_EXP_LDSPAD / 4];
   if (nprob < 0) out[0] = pad[threadIdx.x];
 #endif
