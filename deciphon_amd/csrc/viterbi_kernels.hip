@@ -431,8 +431,11 @@ __global__ __launch_bounds__(64) void dcp_cost_kernel_fused(float const *__restr
 }
 
 // Several windows of one profile per wavefront (viterbi_pack.h): one workgroup = one wavefront = one DcpPack.
+#ifndef DCP_PACK_WAVES
+#define DCP_PACK_WAVES(Q) 1
+#endif
 template <int Q, int S>
-__global__ __launch_bounds__(64) void dcp_cost_pack_kernel(float const *__restrict__ pool,
+__global__ __launch_bounds__(64, DCP_PACK_WAVES(Q)) void dcp_cost_pack_kernel(float const *__restrict__ pool,
                                                            DcpProfileDev const *__restrict__ profiles,
                                                            DcpPack const *__restrict__ packs,
                                                            DcpCodeRow const *__restrict__ code_rows, uint32_t ncode_rows,
