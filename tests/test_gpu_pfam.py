@@ -100,19 +100,19 @@ def test_legacy_encoding_scan_equals_oracle_thread_run(pfam, expected, tmp_path)
 
 
 def test_long_read_against_the_whole_database_like_config5(pfam, orc, tmp_path):
-    """BASELINE configs[4] at database scale in small: a 50 kb read with twelve planted domains carrying 12 %
+    """BASELINE configs[4] at database scale in small: a 25 kb read with twelve planted domains carrying 12 %
     errors (8 % substitutions, 2 % insertions, 2 % deletions) against all 200 profiles -- chained windows
-    (window.c: 50 K nt, the next start moved by the last hit) for every profile below 1000 positions, every
-    product row equal to the oracle-driven thread_run."""
+    (window.c: 50 K nt, the next start moved by the last hit) for every profile below 500 positions, every
+    product row equal to the oracle-driven thread_run.  (test_gpu_scan.py has 50 kb reads against minifam.)"""
     from deciphon_amd import synth
 
     rng = np.random.default_rng(50)
-    x = rng.integers(0, 4, size=50000).astype(np.uint8)
+    x = rng.integers(0, 4, size=25000).astype(np.uint8)
     for j, pi in enumerate(rng.choice(NPROF, size=12, replace=False)):
         cons = pfam.proteins[int(pi)].consensus
         a = int(rng.integers(0, max(len(cons) - 200, 1)))
         dom = synth.mutate(synth.back_translate(cons[a : a + 200]), rng, 0.08, 0.02, 0.02)
-        at = 1000 + j * 4000
+        at = 500 + j * 2000
         x[at : at + len(dom)] = dom
     reads = [(500, "".join("ACGT"[v] for v in x))]
     want = oracle_scan(orc, pfam.proteins, reads, True, False, threads=min(os.cpu_count() or 1, 32))
