@@ -178,6 +178,7 @@ struct dcp_hip
   // problems / results
   DevBuf<DcpProblem> d_problems;
   DevBuf<DcpPack> d_packs;         // cost pass: windows of short profiles, several per wavefront
+  DevBuf<int2> d_pack_groups;      // ... and, for four-lane groups, the packs of one profile that share a workgroup
   DevBuf<float> d_out;
   DevBuf<int64_t> d_aux;           // strip class, literal path pass: table and scratch addresses per window
   DevBuf<int64_t> d_ckpt_addr;     // fast path pass: checkpoint address per window
@@ -199,6 +200,7 @@ struct dcp_hip
   std::vector<DcpProblem> staged_problems; // dcp_hip_stage
   int staged_c_begin[DCP_NUM_CLASSES + 1] = {0};
   int staged_pk_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
+  int staged_pg_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
   double staged_cells = 0;
   int staged_n = -1;
 };
@@ -247,6 +249,8 @@ struct Staged
   int c_begin[DCP_NUM_CLASSES + 1] = {0}; // problems of class c are [c_begin[c], c_begin[c+1])
   std::vector<DcpPack> packs;             // cost pass: sorted by (shape, profile)
   int pk_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
+  std::vector<int2> pack_groups;          // shapes with an LDS variant: {first pack, count} per workgroup
+  int pg_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
   double cells = 0;
   size_t arena_bytes = 0;
 };
@@ -352,6 +356,24 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
     }
     while (shape < DCP_NUM_PACK_SHAPES) st.pk_begin[++shape] = (int)st.packs.size();
     st.problems.swap(rest);
+    // four-lane groups: the packs of one profile go WG to a workgroup, which shares the profile's table in LDS
+    st.pack_groups.clear();
+    char const *lds_env = getenv("DECIPHON_HIP_PACK_LDS");
+    bool const lds_tables = !(lds_env && lds_env[0] == '0');
+    for (int s = 0; s < DCP_NUM_PACK_SHAPES; ++s)
+    {
+      st.pg_begin[s] = (int)st.pack_groups.size();
+      int const wg = lds_tables ? dcp_pack_lds_waves(s) : 0;
+      if (!wg) continue;
+      for (int i = st.pk_begin[s]; i < st.pk_begin[s + 1];)
+      {
+        int j = i;
+        while (j < st.pk_begin[s + 1] && j - i < wg && st.packs[(size_t)j].profile == st.packs[(size_t)i].profile) ++j;
+        st.pack_groups.push_back(make_int2(i - st.pk_begin[s], j - i));
+        i = j;
+      }
+    }
+    st.pg_begin[DCP_NUM_PACK_SHAPES] = (int)st.pack_groups.size();
   }
   int const nu = (int)st.problems.size(); // windows that keep a wavefront (or a workgroup) to themselves
   std::stable_sort(st.problems.begin(), st.problems.end(), [&](DcpProblem const &a, DcpProblem const &b) {
@@ -384,6 +406,13 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
                               x->stream),
             DCP_EFUNCUSE);
     // st.packs is read by the copy until the stream gets there; the callers keep `st` alive across their sync
+    if (!st.pack_groups.empty())
+    {
+      HIP_TRY(x, x->d_pack_groups.reserve(st.pack_groups.size()), DCP_ENOMEM);
+      HIP_TRY(x, hipMemcpyAsync(x->d_pack_groups.p, st.pack_groups.data(), st.pack_groups.size() * sizeof(int2),
+                                hipMemcpyHostToDevice, x->stream),
+              DCP_EFUNCUSE);
+    }
   }
   return 0;
 }
@@ -494,7 +523,13 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
       a.stream = x->pstream[s];
       HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
     }
-    HIP_TRY(x, dcp_launch_cost_pack(s, a, x->d_packs.p + st.pk_begin[s], np, (uint32_t)x->row_off.back()), DCP_EFUNCUSE);
+    int const ng = st.pg_begin[s + 1] - st.pg_begin[s];
+    if (ng > 0)
+      HIP_TRY(x, dcp_launch_cost_pack_lds(s, a, x->d_packs.p + st.pk_begin[s], x->d_pack_groups.p + st.pg_begin[s], ng,
+                                          (uint32_t)x->row_off.back()),
+              DCP_EFUNCUSE);
+    else
+      HIP_TRY(x, dcp_launch_cost_pack(s, a, x->d_packs.p + st.pk_begin[s], np, (uint32_t)x->row_off.back()), DCP_EFUNCUSE);
     if (fork)
     {
       HIP_TRY(x, hipEventRecord(x->pjoin_ev[s], a.stream), DCP_EFUNCUSE);
@@ -1060,6 +1095,7 @@ int dcp_hip_stage(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
   memcpy(x->staged_c_begin, st.c_begin, sizeof(st.c_begin));
   memcpy(x->staged_pk_begin, st.pk_begin, sizeof(st.pk_begin));
+  memcpy(x->staged_pg_begin, st.pg_begin, sizeof(st.pg_begin));
   x->staged_cells = st.cells;
   x->staged_n = n;
   return 0;
@@ -1072,6 +1108,7 @@ int dcp_hip_run_staged(struct dcp_hip *x, int reps, float *ms, double *cells)
   Staged st;
   memcpy(st.c_begin, x->staged_c_begin, sizeof(st.c_begin));
   memcpy(st.pk_begin, x->staged_pk_begin, sizeof(st.pk_begin));
+  memcpy(st.pg_begin, x->staged_pg_begin, sizeof(st.pg_begin));
   hipEvent_t e0, e1;
   HIP_TRY(x, hipEventCreate(&e0), DCP_EFUNCUSE);
   HIP_TRY(x, hipEventCreate(&e1), DCP_EFUNCUSE);

@@ -709,6 +709,14 @@ template <int S> DCP_FN lf group_min(lf v)
   return v;
 }
 
+// EQ consecutive floats of an LDS table at a per-lane float index
+typedef __attribute__((address_space(3))) float lds_float;
+template <int N> DCP_FN void load_lds_q(lds_float const *t, lu idx, lf (&out)[N])
+{
+#pragma unroll
+  for (int q = 0; q < N; ++q) out[q] = t[idx + (uint32_t)q];
+}
+
 // Transition arrays of PackWave that a row needs once (in the fold): parked in LDS, one float4 per lane and
 // array (a wave reads 64 consecutive float4s: no bank conflicts), so that they hold no registers meanwhile.
 DCP_FN float4 *pack_stash_mem()

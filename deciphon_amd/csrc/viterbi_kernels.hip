@@ -450,6 +450,40 @@ __global__ __launch_bounds__(64, DCP_PACK_WAVES(Q)) void dcp_cost_pack_kernel(fl
   w.run(pk.Lmax, out, pk, xt_table);
 }
 
+// The same for groups of four lanes (K <= 12) with the profile's emission table in LDS: a workgroup of WG
+// wavefronts = WG packs of ONE profile (groups[blockIdx] = first pack, number of packs) copies the 1364 rows --
+// header and the 3 Q position columns, DCP_PACK_LDS_ROW(Q) floats each -- once and every wavefront gathers its
+// operands from there (viterbi_pack.h, LDSTAB).
+template <int Q, int WG>
+__global__ __launch_bounds__(64 * WG) void dcp_cost_pack_lds_kernel(float const *__restrict__ pool,
+                                                                   DcpProfileDev const *__restrict__ profiles,
+                                                                   DcpPack const *__restrict__ packs,
+                                                                   int2 const *__restrict__ groups,
+                                                                   DcpCodeRow const *__restrict__ code_rows,
+                                                                   uint32_t ncode_rows, float const *__restrict__ xt_table,
+                                                                   float *__restrict__ out, int ngroups)
+{
+  constexpr int RL = DCP_PACK_LDS_ROW(Q);
+  __shared__ float table[DCP_TABLE_SIZE * RL];
+  if ((int)blockIdx.x >= ngroups) return;
+  int2 const grp = groups[blockIdx.x];
+  DcpProfileDev const pf = profiles[packs[grp.x].profile];
+  float const *__restrict__ rows = pool + pf.rows_off;
+  int const stride = pf.Kp + DCP_ROW_HDR;
+  for (int i = (int)threadIdx.x; i < DCP_TABLE_SIZE * RL; i += 64 * WG)
+  {
+    int const c = i / RL, j = i - c * RL;
+    table[i] = j < DCP_ROW_HDR + 3 * Q ? rows[(size_t)c * stride + j] : __builtin_inff();
+  }
+  __syncthreads();
+  int const wave = (int)(threadIdx.x >> 6);
+  if (wave >= grp.y) return; // no barrier follows
+  DcpPack const &pk = packs[grp.x + wave];
+  PackWave<Q, 4, dcp_lazy_turns(Q), true> w;
+  w.init(pool, pf, code_rows, ncode_rows, xt_table, pk, (lds_float const *)table);
+  w.run(pk.Lmax, out, pk, xt_table);
+}
+
 template <int Q, int W>
 __global__ __launch_bounds__(64 * W) void dcp_path_kernel(float const *__restrict__ pool,
                                                       DcpProfileDev const *__restrict__ profiles,
@@ -844,6 +878,31 @@ hipError_t dcp_launch_cost_pack(int shape, DcpLaunch const &a, DcpPack const *pa
   case 10: return launch_pack_qs<4, 32>(a, packs, npack, ncode_rows);
   default: return hipErrorInvalidValue;
   }
+}
+
+int dcp_pack_lds_waves(int shape) { return shape == 0 || shape == 1 ? 16 : shape == 2 ? 8 : 0; }
+
+hipError_t dcp_launch_cost_pack_lds(int shape, DcpLaunch const &a, DcpPack const *packs, int2 const *groups, int ngroups,
+                                    uint32_t ncode_rows)
+{
+  if (ngroups <= 0) return hipSuccess;
+  switch (shape)
+  {
+  case 0:
+    hipLaunchKernelGGL((dcp_cost_pack_lds_kernel<1, 16>), dim3((unsigned)ngroups), dim3(1024), 0, a.stream, a.pool, a.profiles,
+                       packs, groups, a.code_rows, ncode_rows, a.xt_table, a.out, ngroups);
+    break;
+  case 1:
+    hipLaunchKernelGGL((dcp_cost_pack_lds_kernel<2, 16>), dim3((unsigned)ngroups), dim3(1024), 0, a.stream, a.pool, a.profiles,
+                       packs, groups, a.code_rows, ncode_rows, a.xt_table, a.out, ngroups);
+    break;
+  case 2:
+    hipLaunchKernelGGL((dcp_cost_pack_lds_kernel<4, 8>), dim3((unsigned)ngroups), dim3(512), 0, a.stream, a.pool, a.profiles,
+                       packs, groups, a.code_rows, ncode_rows, a.xt_table, a.out, ngroups);
+    break;
+  default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t dcp_launch_cost_fused(DcpLaunch const &a)

@@ -39,9 +39,17 @@
 #define DCP_SL(P, t) (((P) + 5 - (t)) % 5)
 #endif
 
+// Groups of four lanes (K <= 3 Q) touch sixteen different table rows per load, and a load costs the vector
+// cache a cycle or two per 128-B line whatever it uses of it: those shapes are bound by lines, not by
+// instructions.  Their whole table is small, though -- 1364 rows of 4 + 3 Q floats: 44 / 65 / 87 KB for
+// Q = 1 / 2 / 4 -- so LDSTAB = true reads it from an LDS copy the workgroup shares (dcp_cost_pack_lds_kernel:
+// rows of DCP_PACK_LDS_ROW(Q) floats, header first), where a gather costs bank conflicts only.
+#define DCP_PACK_LDS_ROW(Q) ((Q) == 1 ? 8 : (Q) == 2 ? 12 : 16)
+
 // TURNS = lazy D->D turns taken before the first vote (dcp_lazy_turns, viterbi_body.h)
-template <int Q, int S, int TURNS = dcp_lazy_turns(Q)> struct PackWave
+template <int Q, int S, int TURNS = dcp_lazy_turns(Q), bool LDSTAB = false> struct PackWave
 {
+  static_assert(!LDSTAB || (S == 4 && (Q == 1 || Q == 2 || Q == 4)), "LDS tables: groups of four lanes");
   static_assert(S == 4 || S == 8 || S == 16 || S == 32, "groups of 4, 8, 16 or 32 lanes");
   enum { G = 64 / S, CAP = (S - 1) * Q };
   // Q = 3, 4: the six transition arrays the fold uses once per row wait in LDS (6 KB per wavefront) instead of
@@ -64,6 +72,8 @@ template <int Q, int S, int TURNS = dcp_lazy_turns(Q)> struct PackWave
   lu Lg;                // window length of the lane's group (0: idle group)
   lu crow;              // index of the group's code row 0
   PackSrc src;
+  lds_float const *lds_rows = nullptr; // LDSTAB: the workgroup's copy of the emission table
+  lu lds_off;                          // LDSTAB: float offset of the lane's operands inside a row
 
   lf kBM[STASH ? 1 : Q], kMM[STASH ? 1 : Q], kIM[STASH ? 1 : Q], kDM[STASH ? 1 : Q], kII[STASH ? 1 : Q], kMI[STASH ? 1 : Q];
   DCP_FN void set_fold_trans(lf const (&BM)[Q], lf const (&MM)[Q], lf const (&IM)[Q], lf const (&DM)[Q],
@@ -119,13 +129,18 @@ template <int Q, int S, int TURNS = dcp_lazy_turns(Q)> struct PackWave
 #pragma unroll
     for (int t = 0; t < 5; ++t)
     {
-      load_pack_q<EQ>(src, code[t], em[t]);
+      if constexpr (LDSTAB)
+        load_lds_q<EQ>(lds_rows, code[t] * (uint32_t)DCP_PACK_LDS_ROW(Q) + lds_off, em[t]);
+      else
+        load_pack_q<EQ>(src, code[t], em[t]);
     }
   }
 
   DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, DcpCodeRow const *__restrict__ code_rows,
-                   uint32_t ncode_rows, float const *__restrict__ xt_table, DcpPack const &pk)
+                   uint32_t ncode_rows, float const *__restrict__ xt_table, DcpPack const &pk,
+                   lds_float const *lds_table = nullptr)
   {
+    lds_rows = lds_table;
     lu const lane = lane_ids();
     lu const e = lane & lu_splat((uint32_t)(S - 1)); // lane in its group
     lu const g = lane_shr(lane, S == 4 ? 2 : S == 8 ? 3 : S == 16 ? 4 : 5);
@@ -136,6 +151,7 @@ template <int Q, int S, int TURNS = dcp_lazy_turns(Q)> struct PackWave
     lu const col = lselu(sep, lu_splat((uint32_t)(Kp - Q)), (e - lu_splat(1)) * (uint32_t)Q);
     src = packsrc_make(pool + pf.rows_off, Kp, code_rows, ncode_rows,
                        lselu(sep, lu_splat(0), (col + (uint32_t)DCP_ROW_HDR) * 4u));
+    lds_off = lselu(sep, lu_splat(0), col + (uint32_t)DCP_ROW_HDR);
     float const *__restrict__ trans = pool + pf.trans_off;
     lf BM[Q], MM[Q], MI[Q], IM[Q], II[Q], DM[Q];
     load_cols<Q>(trans + DCP_BM * Kp, col, BM);

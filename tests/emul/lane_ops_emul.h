@@ -316,3 +316,9 @@ template <int Q> inline void pack_unstash_wait(PackFold &, lf (&BM)[Q], lf (&MM)
     MI[q] = em_pack_stash[5][q];
   }
 }
+
+typedef float lds_float;
+template <int N> inline void load_lds_q(lds_float const *t, lu idx, lf (&out)[N])
+{
+  for (int q = 0; q < N; ++q) EM_FOR out[q].v[i_] = t[idx.v[i_] + q];
+}

@@ -15,13 +15,20 @@ KS = (1, 2, 3, 4, 6, 7, 12, 13, 14, 20, 28, 29, 45, 46, 60, 61, 64, 65, 93, 94, 
 
 
 def _both(engine, wins, monkeypatch):
+    """packed (four-lane groups with their table in LDS) == packed with every table in global memory == one
+    window per wavefront, bit for bit"""
     monkeypatch.delenv("DECIPHON_HIP_PACK", raising=False)
+    monkeypatch.delenv("DECIPHON_HIP_PACK_LDS", raising=False)
     packed = engine.cost(wins)
+    monkeypatch.setenv("DECIPHON_HIP_PACK_LDS", "0")
+    nolds = engine.cost(wins)
+    monkeypatch.delenv("DECIPHON_HIP_PACK_LDS")
     monkeypatch.setenv("DECIPHON_HIP_PACK", "0")
     plain = engine.cost(wins)
     monkeypatch.delenv("DECIPHON_HIP_PACK")
-    assert np.array_equal(packed[0].view(np.uint32), plain[0].view(np.uint32))
-    assert np.array_equal(packed[1].view(np.uint32), plain[1].view(np.uint32))
+    for other in (nolds, plain):
+        assert np.array_equal(packed[0].view(np.uint32), other[0].view(np.uint32))
+        assert np.array_equal(packed[1].view(np.uint32), other[1].view(np.uint32))
     return packed
 
 
