@@ -709,12 +709,22 @@ template <int S> DCP_FN lf group_min(lf v)
   return v;
 }
 
-// EQ consecutive floats of an LDS table at a per-lane float index
+// N consecutive floats of an LDS table at a per-lane float index (a multiple of N where N is 2 or 4 and the
+// callers' row length and column offsets are: one ds_read_b64 / b128)
 typedef __attribute__((address_space(3))) float lds_float;
 template <int N> DCP_FN void load_lds_q(lds_float const *t, lu idx, lf (&out)[N])
 {
+  if constexpr (N == 4)
+  {
+    typedef __attribute__((address_space(3))) dcp_f32x4 const *p4;
+    dcp_f32x4 const v = *(p4)(t + idx);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  }
+  else
+  {
 #pragma unroll
-  for (int q = 0; q < N; ++q) out[q] = t[idx + (uint32_t)q];
+    for (int q = 0; q < N; ++q) out[q] = t[idx + (uint32_t)q];
+  }
 }
 
 // Transition arrays of PackWave that a row needs once (in the fold): parked in LDS, one float4 per lane and

@@ -61,9 +61,10 @@ hipError_t dcp_launch_cost_pack(int shape, DcpLaunch const &a, DcpPack const *pa
 // lrt of every window from out[2n] = (null, alt); hits[0] = number of windows with a finite lrt >= 0 (zeroed by
 // the caller), then (window, lrt bits) pairs, unordered
 hipError_t dcp_launch_lrt_filter(float const *out, int n, uint32_t *hits, hipStream_t stream);
-// shapes of four-lane groups (0, 1, 2) with the emission table in LDS: workgroups of dcp_pack_lds_waves(shape)
-// wavefronts, groups[i] = {first pack, number of packs (<= that many, all of one profile)}
-int dcp_pack_lds_waves(int shape); // 0: the shape has no LDS variant
+// the same with the table rows of the short emission lengths in LDS (all five lengths for groups of four lanes):
+// workgroups of dcp_pack_lds_waves(shape) wavefronts, groups[i] = {first pack, number of packs (<= that many,
+// all of one profile)}
+int dcp_pack_lds_waves(int shape); // 0: the shape reads every row from global memory
 hipError_t dcp_launch_cost_pack_lds(int shape, DcpLaunch const &a, DcpPack const *packs, int2 const *groups, int ngroups,
                                     uint32_t ncode_rows);
 // every problem of classes 0..3 (single-wave) in one launch

@@ -450,11 +450,11 @@ __global__ __launch_bounds__(64, DCP_PACK_WAVES(Q)) void dcp_cost_pack_kernel(fl
   w.run(pk.Lmax, out, pk, xt_table);
 }
 
-// The same for groups of four lanes (K <= 12) with the profile's emission table in LDS: a workgroup of WG
-// wavefronts = WG packs of ONE profile (groups[blockIdx] = first pack, number of packs) copies the 1364 rows --
-// header and the 3 Q position columns, DCP_PACK_LDS_ROW(Q) floats each -- once and every wavefront gathers its
-// operands from there (viterbi_pack.h, LDSTAB).
-template <int Q, int WG>
+// The same with the rows of the short emission lengths in LDS (viterbi_pack.h, NLDS): a workgroup of WG
+// wavefronts = WG packs of ONE profile (groups[blockIdx] = first pack, number of packs) copies the first
+// DCP_PACK_LDS_ROWS(NLDS) rows of the profile's table -- header and position columns -- once, and every
+// wavefront gathers those operands from there.
+template <int Q, int S, int WG, int NLDS>
 __global__ __launch_bounds__(64 * WG) void dcp_cost_pack_lds_kernel(float const *__restrict__ pool,
                                                                    DcpProfileDev const *__restrict__ profiles,
                                                                    DcpPack const *__restrict__ packs,
@@ -463,23 +463,23 @@ __global__ __launch_bounds__(64 * WG) void dcp_cost_pack_lds_kernel(float const 
                                                                    uint32_t ncode_rows, float const *__restrict__ xt_table,
                                                                    float *__restrict__ out, int ngroups)
 {
-  constexpr int RL = DCP_PACK_LDS_ROW(Q);
-  __shared__ float table[DCP_TABLE_SIZE * RL];
+  constexpr int RL = DCP_PACK_LDS_ROW(Q, S), NR = DCP_PACK_LDS_ROWS(NLDS);
+  __shared__ __attribute__((aligned(16))) float table[NR * RL];
   if ((int)blockIdx.x >= ngroups) return;
   int2 const grp = groups[blockIdx.x];
   DcpProfileDev const pf = profiles[packs[grp.x].profile];
   float const *__restrict__ rows = pool + pf.rows_off;
   int const stride = pf.Kp + DCP_ROW_HDR;
-  for (int i = (int)threadIdx.x; i < DCP_TABLE_SIZE * RL; i += 64 * WG)
+  for (int i = (int)threadIdx.x; i < NR * RL; i += 64 * WG)
   {
     int const c = i / RL, j = i - c * RL;
-    table[i] = j < DCP_ROW_HDR + 3 * Q ? rows[(size_t)c * stride + j] : __builtin_inff();
+    table[i] = j < stride ? rows[(size_t)c * stride + j] : __builtin_inff();
   }
   __syncthreads();
   int const wave = (int)(threadIdx.x >> 6);
   if (wave >= grp.y) return; // no barrier follows
   DcpPack const &pk = packs[grp.x + wave];
-  PackWave<Q, 4, dcp_lazy_turns(Q), true> w;
+  PackWave<Q, S, dcp_lazy_turns(Q), NLDS> w;
   w.init(pool, pf, code_rows, ncode_rows, xt_table, pk, (lds_float const *)table);
   w.run(pk.Lmax, out, pk, xt_table);
 }
@@ -880,29 +880,39 @@ hipError_t dcp_launch_cost_pack(int shape, DcpLaunch const &a, DcpPack const *pa
   }
 }
 
-int dcp_pack_lds_waves(int shape) { return shape == 0 || shape == 1 ? 16 : shape == 2 ? 8 : 0; }
+// wavefronts per workgroup of the LDS variants, by shape: as many as the registers let a CU hold.  Groups of 32
+// lanes keep every row in L2: two rows per load are not what binds them, and the LDS variants measured 3-5 %
+// slower there (K = 93: 711 against 745 GCUPS) while groups of 8 and 16 gained up to 27 % (K = 28: 580 -> 737).
+static int const pack_lds_wg[DCP_NUM_PACK_SHAPES] = {16, 16, 8, 16, 8, 16, 12, 8, 0, 0, 0};
+int dcp_pack_lds_waves(int shape) { return shape >= 0 && shape < DCP_NUM_PACK_SHAPES ? pack_lds_wg[shape] : 0; }
+
+template <int Q, int S, int WG, int NLDS>
+static hipError_t launch_pack_lds(DcpLaunch const &a, DcpPack const *packs, int2 const *groups, int ngroups, uint32_t ncode_rows)
+{
+  hipLaunchKernelGGL((dcp_cost_pack_lds_kernel<Q, S, WG, NLDS>), dim3((unsigned)ngroups), dim3(64 * WG), 0, a.stream, a.pool,
+                     a.profiles, packs, groups, a.code_rows, ncode_rows, a.xt_table, a.out, ngroups);
+  return hipGetLastError();
+}
 
 hipError_t dcp_launch_cost_pack_lds(int shape, DcpLaunch const &a, DcpPack const *packs, int2 const *groups, int ngroups,
                                     uint32_t ncode_rows)
 {
   if (ngroups <= 0) return hipSuccess;
-  switch (shape)
+  switch (shape) // (Q, S, wavefronts, emission lengths in LDS): LDS bytes
   {
-  case 0:
-    hipLaunchKernelGGL((dcp_cost_pack_lds_kernel<1, 16>), dim3((unsigned)ngroups), dim3(1024), 0, a.stream, a.pool, a.profiles,
-                       packs, groups, a.code_rows, ncode_rows, a.xt_table, a.out, ngroups);
-    break;
-  case 1:
-    hipLaunchKernelGGL((dcp_cost_pack_lds_kernel<2, 16>), dim3((unsigned)ngroups), dim3(1024), 0, a.stream, a.pool, a.profiles,
-                       packs, groups, a.code_rows, ncode_rows, a.xt_table, a.out, ngroups);
-    break;
-  case 2:
-    hipLaunchKernelGGL((dcp_cost_pack_lds_kernel<4, 8>), dim3((unsigned)ngroups), dim3(512), 0, a.stream, a.pool, a.profiles,
-                       packs, groups, a.code_rows, ncode_rows, a.xt_table, a.out, ngroups);
-    break;
+  case 0: return launch_pack_lds<1, 4, 16, 5>(a, packs, groups, ngroups, ncode_rows);  // 44 KB
+  case 1: return launch_pack_lds<2, 4, 16, 5>(a, packs, groups, ngroups, ncode_rows);  // 65 KB
+  case 2: return launch_pack_lds<4, 4, 8, 5>(a, packs, groups, ngroups, ncode_rows);   // 87 KB
+  case 3: return launch_pack_lds<2, 8, 16, 4>(a, packs, groups, ngroups, ncode_rows);  // 27 KB
+  case 4: return launch_pack_lds<4, 8, 8, 4>(a, packs, groups, ngroups, ncode_rows);   // 44 KB
+  case 5: return launch_pack_lds<2, 16, 16, 4>(a, packs, groups, ngroups, ncode_rows); // 49 KB
+  case 6: return launch_pack_lds<3, 16, 12, 4>(a, packs, groups, ngroups, ncode_rows); // 71 KB
+  case 7: return launch_pack_lds<4, 16, 8, 4>(a, packs, groups, ngroups, ncode_rows);  // 87 KB
+  case 8: return launch_pack_lds<2, 32, 16, 4>(a, packs, groups, ngroups, ncode_rows); // 92 KB
+  case 9: return launch_pack_lds<3, 32, 12, 4>(a, packs, groups, ngroups, ncode_rows); // 136 KB
+  case 10: return launch_pack_lds<4, 32, 8, 3>(a, packs, groups, ngroups, ncode_rows); // 43 KB: lengths 1..3 only
   default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 
 hipError_t dcp_launch_cost_fused(DcpLaunch const &a)

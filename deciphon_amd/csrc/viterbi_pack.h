@@ -39,17 +39,21 @@
 #define DCP_SL(P, t) (((P) + 5 - (t)) % 5)
 #endif
 
-// Groups of four lanes (K <= 3 Q) touch sixteen different table rows per load, and a load costs the vector
-// cache a cycle or two per 128-B line whatever it uses of it: those shapes are bound by lines, not by
-// instructions.  Their whole table is small, though -- 1364 rows of 4 + 3 Q floats: 44 / 65 / 87 KB for
-// Q = 1 / 2 / 4 -- so LDSTAB = true reads it from an LDS copy the workgroup shares (dcp_cost_pack_lds_kernel:
-// rows of DCP_PACK_LDS_ROW(Q) floats, header first), where a gather costs bank conflicts only.
-#define DCP_PACK_LDS_ROW(Q) ((Q) == 1 ? 8 : (Q) == 2 ? 12 : 16)
+// A load costs the vector cache a cycle or two per 128-B line it touches, whatever it uses of the line, and a
+// pack touches G different table rows per load: the packed kernels are bound by lines, not by instructions
+// (profiles/r02_exp_*).  So the rows of the SHORT emission lengths are read from an LDS copy the workgroup
+// shares (dcp_cost_pack_lds_kernel) -- a gather there costs bank conflicts only.  NLDS = emission lengths
+// served from LDS: the codes of lengths 1..NLDS are the first 4, 20, 84, 340, 1364 rows of the table, so
+// NLDS = 5 is the whole table (groups of four lanes: 44-87 KB), NLDS = 4 leaves the 1024 five-mer rows in L2
+// (340 rows: 27-136 KB for groups of 8..32 lanes), NLDS = 3 keeps 84 rows.  LDS rows hold the header and the
+// (S - 1) Q position columns, DCP_PACK_LDS_ROW(Q, S) floats.
+#define DCP_PACK_LDS_ROW(Q, S) ((DCP_ROW_HDR + ((S)-1) * (Q) + 3) / 4 * 4)
+#define DCP_PACK_LDS_ROWS(NLDS) ((NLDS) == 5 ? 1364 : (NLDS) == 4 ? 340 : (NLDS) == 3 ? 84 : (NLDS) == 2 ? 20 : 4)
 
 // TURNS = lazy D->D turns taken before the first vote (dcp_lazy_turns, viterbi_body.h)
-template <int Q, int S, int TURNS = dcp_lazy_turns(Q), bool LDSTAB = false> struct PackWave
+template <int Q, int S, int TURNS = dcp_lazy_turns(Q), int NLDS = 0> struct PackWave
 {
-  static_assert(!LDSTAB || (S == 4 && (Q == 1 || Q == 2 || Q == 4)), "LDS tables: groups of four lanes");
+  static constexpr bool LDSTAB = NLDS > 0;
   static_assert(S == 4 || S == 8 || S == 16 || S == 32, "groups of 4, 8, 16 or 32 lanes");
   enum { G = 64 / S, CAP = (S - 1) * Q };
   // Q = 3, 4: the six transition arrays the fold uses once per row wait in LDS (6 KB per wavefront) instead of
@@ -129,8 +133,8 @@ template <int Q, int S, int TURNS = dcp_lazy_turns(Q), bool LDSTAB = false> stru
 #pragma unroll
     for (int t = 0; t < 5; ++t)
     {
-      if constexpr (LDSTAB)
-        load_lds_q<EQ>(lds_rows, code[t] * (uint32_t)DCP_PACK_LDS_ROW(Q) + lds_off, em[t]);
+      if (t < NLDS) // the codes of emission length t + 1 are rows < DCP_PACK_LDS_ROWS(t + 1)
+        load_lds_q<EQ>(lds_rows, code[t] * (uint32_t)DCP_PACK_LDS_ROW(Q, S) + lds_off, em[t]);
       else
         load_pack_q<EQ>(src, code[t], em[t]);
     }

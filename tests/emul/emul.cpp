@@ -205,30 +205,38 @@ static void pack_qs(float const *pool, DcpProfileDev const &pf, DcpCodeRow const
   w.run(pk.Lmax, out, pk, xt_table);
 }
 
-// the same through the LDS copy of the table (groups of four lanes): rows of DCP_PACK_LDS_ROW(Q) floats
-template <int Q>
+// the same with the rows of the first NLDS emission lengths read from an "LDS" copy of the table
+template <int Q, int S, int NLDS>
 static void pack_lds_q(float const *pool, DcpProfileDev const &pf, DcpCodeRow const *codes, uint32_t ncodes, float const *xt_table,
                        DcpPack const &pk, float *out)
 {
-  int const RL = DCP_PACK_LDS_ROW(Q);
-  std::vector<float> table((size_t)DCP_TABLE_SIZE * RL, INFINITY);
-  for (int c = 0; c < DCP_TABLE_SIZE; ++c)
-    for (int j = 0; j < RL && j < DCP_ROW_HDR + 3 * Q; ++j)
+  int const RL = DCP_PACK_LDS_ROW(Q, S), NR = DCP_PACK_LDS_ROWS(NLDS);
+  std::vector<float> table((size_t)NR * RL, INFINITY);
+  for (int c = 0; c < NR; ++c)
+    for (int j = 0; j < RL && j < pf.Kp + DCP_ROW_HDR; ++j)
       table[(size_t)c * RL + j] = pool[pf.rows_off + (size_t)c * (pf.Kp + DCP_ROW_HDR) + j];
-  static thread_local PackWave<Q, 4, dcp_lazy_turns(Q), true> w;
+  static thread_local PackWave<Q, S, dcp_lazy_turns(Q), NLDS> w;
   em_lanes = 64;
   w.init(pool, pf, codes, ncodes, xt_table, pk, table.data());
   w.run(pk.Lmax, out, pk, xt_table);
 }
 
-extern "C" int emul_cost_pack_lds(int Q, float const *pool, DcpProfileDev const *pf, DcpCodeRow const *codes, uint32_t ncodes,
-                                  float const *xt_table, DcpPack const *pk, float *out)
+extern "C" int emul_cost_pack_lds(int Q, int S, float const *pool, DcpProfileDev const *pf, DcpCodeRow const *codes,
+                                  uint32_t ncodes, float const *xt_table, DcpPack const *pk, float *out)
 {
-  switch (Q)
+  switch (Q * 100 + S)
   {
-  case 1: pack_lds_q<1>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
-  case 2: pack_lds_q<2>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
-  case 4: pack_lds_q<4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 104: pack_lds_q<1, 4, 5>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 204: pack_lds_q<2, 4, 5>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 404: pack_lds_q<4, 4, 5>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 208: pack_lds_q<2, 8, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 408: pack_lds_q<4, 8, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 216: pack_lds_q<2, 16, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 316: pack_lds_q<3, 16, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 416: pack_lds_q<4, 16, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 232: pack_lds_q<2, 32, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 332: pack_lds_q<3, 32, 4>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
+  case 432: pack_lds_q<4, 32, 3>(pool, *pf, codes, ncodes, xt_table, *pk, out); return 0;
   default: return -1;
   }
 }

@@ -280,9 +280,9 @@ def run_pack(em, orc, prof, S, Q, seqs, mh=True, h3=False, quant=None):
         pk.L[g], pk.xt_row[g], pk.out[g], pk.code_row[g] = len(s), max(len(s) // 3, 1), g, first[g]
     assert em.emul_cost_pack(Q, S, _vp(pool), C.byref(pd), _vp(rows), len(rows), _vp(xt), C.byref(pk), _vp(out)) == 0
     assert np.all(out[len(seqs):] == np.float32(-7.0))
-    if S == 4:  # the same windows through the LDS copy of the table: the same bits
+    if Q <= 4:  # the same windows with the short emission lengths' rows read from the LDS copy: the same bits
         out2 = np.full_like(out, np.float32(-7.0))
-        assert em.emul_cost_pack_lds(Q, _vp(pool), C.byref(pd), _vp(rows), len(rows), _vp(xt), C.byref(pk), _vp(out2)) == 0
+        assert em.emul_cost_pack_lds(Q, S, _vp(pool), C.byref(pd), _vp(rows), len(rows), _vp(xt), C.byref(pk), _vp(out2)) == 0
         assert np.array_equal(out.view(np.uint32), out2.view(np.uint32))
     return out[: len(seqs)], xt
 
