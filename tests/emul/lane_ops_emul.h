@@ -77,7 +77,7 @@ inline uint32_t read_laneu(lu x, int lane) { return x.v[lane]; }
 enum { GS_M, GS_I, GS_D, GS_E, GS_F, GS_X, GS_T0, GS_T1, GS_X0, GS_X1, GS_SLOTS };
 
 // rows of the cost pass that took the exchange-until-stable fallback (tests read and reset it)
-static thread_local long em_fallback_rows = 0;
+extern thread_local long em_fallback_rows; // defined in emul.cpp: one counter for every translation unit
 
 template <int W> struct Group
 {
