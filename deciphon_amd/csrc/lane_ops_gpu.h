@@ -632,6 +632,20 @@ template <int S> DCP_FN lf group_bcast0(lf x)
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (~(S - 1)) & 0x1f));
 }
 
+// r[t] = s[t] + e[t] of lane 0 of the quad, t = 0..4: the quad broadcast rides as the DPP operand of the add (the
+// compiler keeps a v_mov_b32_dpp per operand here).  A DPP source wants two wait states after a VALU write.
+DCP_FN void add_quad0_x5(lf (&r)[5], lf const (&s)[5], lf const (&e)[5])
+{
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %5, %10 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %6, %11 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %7, %12 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %3, %8, %13 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %4, %9, %14 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4])
+      : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]));
+}
+
 template <int Q> DCP_FN void load_pack_q(PackSrc const &s, lu code, lf (&out)[Q]);
 template <> DCP_FN void load_pack_q<1>(PackSrc const &s, lu code, lf (&out)[1])
 {
@@ -686,7 +700,7 @@ DCP_FN void store_f32_where(float *__restrict__ p, lu i, lm m, lf v)
 
 // min over the S lanes of each group, returned to every lane of the group.  Butterfly inside a row of 16
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: DPP operands of v_min_f32); groups of 32 then take
-// the other row of their pair through row_bcast:15 and two readlanes.
+// the other row of their pair with a ds_swizzle.
 #define DCP_DPP_MIN(v, ctrl) \
   __builtin_fminf((v), __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, true)))
 template <int S> DCP_FN lf group_min(lf v)
@@ -697,17 +711,15 @@ template <int S> DCP_FN lf group_min(lf v)
   if (S >= 16) v = DCP_DPP_MIN(v, 0x140); // row_mirror
   if (S == 32)
   {
-    // every row is uniform now; rows 1 and 3 take the minimum with the row before them ...
-    lf const t = __int_as_float(
-        __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xa, 0xf, false)); // row_bcast:15
-    lf const u = __builtin_fminf(v, t);
-    // ... and hand it to both rows of their group
-    float const lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 31));
-    float const hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 63));
-    v = (lane_ids() & 32u) ? hi : lo;
+    // every row is uniform now: take the other row of the pair (ds_swizzle, lane ^ 16: the LDS pipe, no memory)
+    lf const t = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401f));
+    v = __builtin_fminf(v, t);
   }
   return v;
 }
+
+// min(v[lane 0], v[lane 1]) of every group, in all its lanes: one quad DPP step and the group broadcast
+template <int S> DCP_FN lf group_min01(lf v) { return group_bcast0<S>(DCP_DPP_MIN(v, 0xB1)); }
 
 // N consecutive floats of an LDS table at a per-lane float index (a multiple of N where N is 2 or 4 and the
 // callers' row length and column offsets are: one ds_read_b64 / b128)

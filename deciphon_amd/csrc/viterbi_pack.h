@@ -207,13 +207,15 @@ template <int Q, int S, int TURNS = dcp_lazy_turns(Q), int NLDS = 0> struct Pack
   template <int P> DCP_FN void row(int l, int Lmax)
   {
     lf M[Q], I[Q], D[Q];
-    lf nil[5], bgv[5];
+    lf bgv[5], hdr[5], sp[5], xs[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
     {
-      nil[t] = quad_bcast0(em[t][0]);     // lanes e = 0..3 (the special states): null[c_t] of their group
       bgv[t] = group_bcast0<S>(em[t][1]); // every lane: bg[c_t] of its group
+      hdr[t] = em[t][0];                  // the separator's: null[c_t] of the group
+      sp[t] = Spre[DCP_SL(P, t + 1)];
     }
+    add_quad0_x5(xs, sp, hdr); // lanes e = 0..3 (the special states) add null[c_t] of their group
 #pragma unroll
     for (int q = 0; q < Q; ++q)
     {
@@ -224,8 +226,7 @@ template <int Q, int S, int TURNS = dcp_lazy_turns(Q), int NLDS = 0> struct Pack
                          Ipre[DCP_SL(P, 3)][q] + bgv[2]),
                    Ipre[DCP_SL(P, 2)][q] + bgv[1], Ipre[DCP_SL(P, 1)][q] + bgv[0]);
     }
-    X = lmin3(lmin3(Spre[DCP_SL(P, 5)] + nil[4], Spre[DCP_SL(P, 4)] + nil[3], Spre[DCP_SL(P, 3)] + nil[2]),
-              Spre[DCP_SL(P, 2)] + nil[1], Spre[DCP_SL(P, 1)] + nil[0]);
+    X = lmin3(lmin3(xs[4], xs[3], xs[2]), xs[1], xs[0]);
 
     // this row's operands are consumed: the next row's (its codes arrived a row ago) go out now,
     // together with the codes of the row after it
@@ -241,7 +242,7 @@ template <int Q, int S, int TURNS = dcp_lazy_turns(Q), int NLDS = 0> struct Pack
     lf const Msh0 = lane_shift_up_keep(M[Q - 1], shM);
     lf const Ish0 = lane_shift_up_keep(I[Q - 1], shI);
     E = group_min<S>(m);                                   // E_l = min_k M_l[k] (see viterbi_body.h)
-    lf const B = lmin(E + EBv, group_min<S>(X + nbjb));    // c-core/viterbi.c:495-496,582-583
+    lf const B = lmin(E + EBv, group_min01<S>(X + nbjb)); // c-core/viterbi.c:495-496,582-583 (N, J: lanes 0, 1)
 
     PackFold fold;
     if constexpr (STASH) pack_unstash_issue(fold); // back from LDS while the D chain runs

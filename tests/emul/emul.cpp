@@ -6,6 +6,7 @@
 #include "../../deciphon_amd/csrc/traceback.h"
 
 thread_local long em_fallback_rows = 0;
+thread_local long em_votes = 0, em_votes_true = 0;
 
 template <int Q, int W>
 static void cost_q(float const *pool, DcpProfileDev const &pf, DcpCodeRow const *codes, int L, float const *xt, float *out)
@@ -51,3 +52,11 @@ extern "C" long emul_fallback_rows(void)
   return n;
 }
 
+
+// votes of the lazy D->D loops since the last call: out[0] = taken, out[1] = carried (one more turn each)
+extern "C" void emul_votes(long *out)
+{
+  out[0] = em_votes;
+  out[1] = em_votes_true;
+  em_votes = em_votes_true = 0;
+}

@@ -69,7 +69,14 @@ inline lf lf_pin(float x) { return lf_splat(x); }
 
 inline float wave_min(lf v) { float m = v.v[0]; EM_FOR m = fminf(m, v.v[i_]); return m; }
 inline uint32_t wave_minu(lu v) { uint32_t m = v.v[0]; EM_FOR m = v.v[i_] < m ? v.v[i_] : m; return m; }
-inline bool wave_any(lm m) { EM_FOR if (m.v[i_]) return true; return false; }
+// votes taken / votes that carried since the last emul_votes() call (diagnostic: extra lazy D->D turns per row)
+extern thread_local long em_votes, em_votes_true;
+inline bool wave_any(lm m)
+{
+  ++em_votes;
+  EM_FOR if (m.v[i_]) { ++em_votes_true; return true; }
+  return false;
+}
 inline uint64_t wave_ballot(lm m) { uint64_t b = 0; EM_FOR if (m.v[i_]) b |= 1ull << i_; return b; }
 inline float read_lane(lf x, int lane) { return x.v[lane]; }
 inline uint32_t read_laneu(lu x, int lane) { return x.v[lane]; }
@@ -297,6 +304,17 @@ template <int S> inline lf group_min(lf v)
     for (int i = g * S; i < g * S + S; ++i) m = fminf(m, v.v[i]);
     for (int i = g * S; i < g * S + S; ++i) r.v[i] = m;
   }
+  return r;
+}
+
+inline void add_quad0_x5(lf (&r)[5], lf const (&s)[5], lf const (&e)[5])
+{
+  for (int t = 0; t < 5; ++t) r[t] = s[t] + quad_bcast0(e[t]);
+}
+template <int S> inline lf group_min01(lf v)
+{
+  lf r;
+  EM_FOR r.v[i_] = fminf(v.v[i_ & ~(S - 1)], v.v[(i_ & ~(S - 1)) + 1]);
   return r;
 }
 
