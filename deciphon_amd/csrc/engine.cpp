@@ -126,6 +126,7 @@ struct HostProfile
 {
   int K, Kp, Q, W, cls;
   int pack = -1; // shape of the packed cost kernel (several windows per wavefront), -1: none
+  bool narrow = false; // fits its class with one position per lane less (dcp_class_narrow_limit)
   int64_t pool_off; // floats
   std::string accession;
 };
@@ -152,6 +153,8 @@ struct dcp_hip
   hipEvent_t fork_ev = nullptr, join_ev[DCP_NUM_CLASSES] = {nullptr};
   hipStream_t pstream[DCP_NUM_PACK_SHAPES] = {nullptr}; // the packed cost kernels, one stream per shape
   hipEvent_t pjoin_ev[DCP_NUM_PACK_SHAPES] = {nullptr};
+  hipStream_t nstream[DCP_NUM_CLASSES] = {nullptr};     // the narrow cost kernels of classes 4..6
+  hipEvent_t njoin_ev[DCP_NUM_CLASSES] = {nullptr};
   std::string err;
 
   // profiles
@@ -199,6 +202,7 @@ struct dcp_hip
   std::vector<PathResult> paths;
   std::vector<DcpProblem> staged_problems; // dcp_hip_stage
   int staged_c_begin[DCP_NUM_CLASSES + 1] = {0};
+  int staged_c_wide[DCP_NUM_CLASSES] = {0};
   int staged_pk_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
   int staged_pg_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
   double staged_cells = 0;
@@ -247,6 +251,7 @@ struct Staged
 {
   std::vector<DcpProblem> problems;       // sorted by (class, profile); cost pass: without the packed ones
   int c_begin[DCP_NUM_CLASSES + 1] = {0}; // problems of class c are [c_begin[c], c_begin[c+1])
+  int c_wide[DCP_NUM_CLASSES] = {0};      // ... the narrow profiles' first: [c_begin[c], c_wide[c])
   std::vector<DcpPack> packs;             // cost pass: sorted by (shape, profile)
   int pk_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
   std::vector<int2> pack_groups;          // shapes with an LDS variant: {first pack, count} per workgroup
@@ -377,14 +382,19 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
   }
   int const nu = (int)st.problems.size(); // windows that keep a wavefront (or a workgroup) to themselves
   std::stable_sort(st.problems.begin(), st.problems.end(), [&](DcpProblem const &a, DcpProblem const &b) {
-    int ca = x->profiles[(size_t)a.profile].cls, cb = x->profiles[(size_t)b.profile].cls;
-    if (ca != cb) return ca < cb;
+    HostProfile const &pa = x->profiles[(size_t)a.profile], &pb = x->profiles[(size_t)b.profile];
+    if (pa.cls != pb.cls) return pa.cls < pb.cls;
+    if (pa.narrow != pb.narrow) return pa.narrow; // one position per lane less: their own launch of the cost pass
     return a.profile < b.profile;
   });
   int i = 0;
   for (int c = 0; c < DCP_NUM_CLASSES; ++c)
   {
     st.c_begin[c] = i;
+    while (i < nu && x->profiles[(size_t)st.problems[(size_t)i].profile].cls == c &&
+           x->profiles[(size_t)st.problems[(size_t)i].profile].narrow)
+      ++i;
+    st.c_wide[c] = i;
     while (i < nu && x->profiles[(size_t)st.problems[(size_t)i].profile].cls == c) ++i;
   }
   st.c_begin[DCP_NUM_CLASSES] = i;
@@ -474,6 +484,9 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
   int kernels = fused ? 1 : 0;
   for (int c = fused ? 4 : 0; c < DCP_NUM_CLASSES; ++c) kernels += st.c_begin[c + 1] > st.c_begin[c];
   for (int s = 0; s < DCP_NUM_PACK_SHAPES; ++s) kernels += st.pk_begin[s + 1] > st.pk_begin[s];
+  char const *narrow_env = getenv("DECIPHON_HIP_NARROW");
+  bool const narrow = !(narrow_env && narrow_env[0] == '0');
+  for (int c = 4; narrow && c < DCP_NUM_CLASSES; ++c) kernels += st.c_wide[c] > st.c_begin[c];
   bool const fork = kernels > 1;
   if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
   // Launch order = start order (the hardware runs a few queues side by side and takes kernels as they come):
@@ -490,7 +503,28 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
       b.stream = x->qstream[c];
       HIP_TRY(x, hipStreamWaitEvent(b.stream, x->fork_ev, 0), DCP_EFUNCUSE);
     }
-    HIP_TRY(x, dcp_launch_cost(c, b), DCP_EFUNCUSE);
+    // the windows that fit with one position per lane less (dcp_class_narrow_limit) lead the class's list and have
+    // their own kernel, on its own stream.  DECIPHON_HIP_NARROW=0: the class's kernel for all (tests compare).
+    int const nn = narrow ? st.c_wide[c] - st.c_begin[c] : 0;
+    if (nn > 0)
+    {
+      DcpLaunch n = b;
+      n.nprob = nn;
+      if (fork)
+      {
+        n.stream = x->nstream[c];
+        HIP_TRY(x, hipStreamWaitEvent(n.stream, x->fork_ev, 0), DCP_EFUNCUSE);
+      }
+      HIP_TRY(x, dcp_launch_cost_narrow(c, n), DCP_EFUNCUSE);
+      if (fork)
+      {
+        HIP_TRY(x, hipEventRecord(x->njoin_ev[c], n.stream), DCP_EFUNCUSE);
+        HIP_TRY(x, hipStreamWaitEvent(x->stream, x->njoin_ev[c], 0), DCP_EFUNCUSE);
+      }
+      b.problems += nn;
+      b.nprob -= nn;
+    }
+    if (b.nprob > 0) HIP_TRY(x, dcp_launch_cost(c, b), DCP_EFUNCUSE);
     if (fork)
     {
       HIP_TRY(x, hipEventRecord(x->join_ev[c], b.stream), DCP_EFUNCUSE);
@@ -572,6 +606,11 @@ struct dcp_hip *dcp_hip_new(int device)
     ok = ok && hipStreamCreateWithFlags(&x->pstream[c], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&x->pjoin_ev[c], hipEventDisableTiming) == hipSuccess;
   }
+  for (int c = 4; ok && c <= 6; ++c)
+  {
+    ok = ok && hipStreamCreateWithFlags(&x->nstream[c], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&x->njoin_ev[c], hipEventDisableTiming) == hipSuccess;
+  }
   if (!ok)
   {
     dcp_hip_del(x);
@@ -596,6 +635,11 @@ void dcp_hip_del(struct dcp_hip *x)
   {
     if (x->pstream[c]) (void)hipStreamDestroy(x->pstream[c]);
     if (x->pjoin_ev[c]) (void)hipEventDestroy(x->pjoin_ev[c]);
+  }
+  for (int c = 0; c < DCP_NUM_CLASSES; ++c)
+  {
+    if (x->nstream[c]) (void)hipStreamDestroy(x->nstream[c]);
+    if (x->njoin_ev[c]) (void)hipEventDestroy(x->njoin_ev[c]);
   }
   if (x->fork_ev) (void)hipEventDestroy(x->fork_ev);
   if (x->stream) (void)hipStreamDestroy(x->stream);
@@ -626,6 +670,7 @@ static int describe(dcp_hip *x, int K, char const *accession, HostProfile &hp)
   if (cls == DCP_STRIP_CLASS) hp.Kp *= (K + hp.Kp - 1) / hp.Kp; // whole strips
   hp.pool_off = 0;
   hp.accession = accession ? accession : "";
+  hp.narrow = K <= dcp_class_narrow_limit(cls);
   hp.pack = dcp_pack_shape_of(K);
   if (hp.pack >= 0)
   {
@@ -1094,6 +1139,7 @@ int dcp_hip_stage(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
   memcpy(x->staged_c_begin, st.c_begin, sizeof(st.c_begin));
+  memcpy(x->staged_c_wide, st.c_wide, sizeof(st.c_wide));
   memcpy(x->staged_pk_begin, st.pk_begin, sizeof(st.pk_begin));
   memcpy(x->staged_pg_begin, st.pg_begin, sizeof(st.pg_begin));
   x->staged_cells = st.cells;
@@ -1107,6 +1153,7 @@ int dcp_hip_run_staged(struct dcp_hip *x, int reps, float *ms, double *cells)
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   Staged st;
   memcpy(st.c_begin, x->staged_c_begin, sizeof(st.c_begin));
+  memcpy(st.c_wide, x->staged_c_wide, sizeof(st.c_wide));
   memcpy(st.pk_begin, x->staged_pk_begin, sizeof(st.pk_begin));
   memcpy(st.pg_begin, x->staged_pg_begin, sizeof(st.pg_begin));
   hipEvent_t e0, e1;

@@ -423,6 +423,18 @@ template <> DCP_FN void load_q<4>(float const *__restrict__ row, lu lane, lf (&o
   out[3] = v.w;
 }
 
+template <> DCP_FN void load_q<5>(float const *__restrict__ row, lu lane, lf (&out)[5])
+{
+  float const *p = row + (size_t)lane * 5; // 20-byte elements, 4-byte aligned
+#pragma unroll
+  for (int q = 0; q < 5; ++q) out[q] = p[q];
+}
+template <> DCP_FN void load_q<7>(float const *__restrict__ row, lu lane, lf (&out)[7])
+{
+  float const *p = row + (size_t)lane * 7;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) out[q] = p[q];
+}
 template <> DCP_FN void load_q<6>(float const *__restrict__ row, lu lane, lf (&out)[6])
 {
   float2 const *p = reinterpret_cast<float2 const *>(row + (size_t)lane * 6); // 24-byte elements, 8-byte aligned
@@ -494,6 +506,21 @@ template <> DCP_FN void load_row_q<4>(RowSrc const &r, lu voff, uint32_t soff, l
   out[3] = __uint_as_float(v.w);
 }
 
+template <> DCP_FN void load_row_q<5>(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[5])
+{
+  dcp_u32x4 const a = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, voff, soff, 0);
+  out[0] = __uint_as_float(a.x); out[1] = __uint_as_float(a.y); out[2] = __uint_as_float(a.z);
+  out[3] = __uint_as_float(a.w);
+  out[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r.rsrc, voff + 16u, soff, 0));
+}
+template <> DCP_FN void load_row_q<7>(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[7])
+{
+  dcp_u32x4 const a = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, voff, soff, 0);
+  dcp_u32x3 const b = __builtin_amdgcn_raw_buffer_load_b96(r.rsrc, voff + 16u, soff, 0);
+  out[0] = __uint_as_float(a.x); out[1] = __uint_as_float(a.y); out[2] = __uint_as_float(a.z);
+  out[3] = __uint_as_float(a.w); out[4] = __uint_as_float(b.x); out[5] = __uint_as_float(b.y);
+  out[6] = __uint_as_float(b.z);
+}
 template <> DCP_FN void load_row_q<6>(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[6])
 {
   dcp_u32x4 const a = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, voff, soff, 0);

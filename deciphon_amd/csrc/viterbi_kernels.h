@@ -41,6 +41,8 @@ struct DcpLaunch
 };
 
 hipError_t dcp_launch_cost(int cls, DcpLaunch const &a);
+int dcp_class_narrow_limit(int cls);                             // core sizes up to it run one position per lane less (0: none)
+hipError_t dcp_launch_cost_narrow(int cls, DcpLaunch const &a); // cost pass of those windows
 hipError_t dcp_launch_path(int cls, DcpLaunch const &a);
 // trellis_unzip of every problem of a.problems (all classes): steps[step_off[out] .. step_off[out+1]) is the
 // buffer of problem `out`; its steps end at the buffer's end

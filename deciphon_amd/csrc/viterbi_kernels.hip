@@ -769,6 +769,24 @@ hipError_t dcp_launch_cost(int cls, DcpLaunch const &a)
   }
 }
 
+// The classes whose rows are padded to 384, 512 and 768 columns: a profile that fits with one position per lane
+// less -- K <= 320 in (5,1) instead of (6,1), K <= 448 in (7,1) instead of (8,1), K <= 640 in (5,2) instead of
+// (6,2) -- runs that way on the same tables (it reads the first 64 Q W columns of a row): a sixth or an eighth
+// fewer instructions per row.  The engine sorts those windows to the front of their class.
+int dcp_class_narrow_limit(int cls) { return cls == 4 ? 320 : cls == 5 ? 448 : cls == 6 ? 640 : 0; }
+
+hipError_t dcp_launch_cost_narrow(int cls, DcpLaunch const &a)
+{
+  if (a.nprob <= 0) return hipSuccess;
+  switch (cls)
+  {
+  case 4: return launch_cost_qw<5, 1>(a);
+  case 5: return launch_cost_qw<7, 1>(a);
+  case 6: return launch_cost_qw<5, 2>(a);
+  default: return hipErrorInvalidValue;
+  }
+}
+
 template <int Q, int W> static hipError_t launch_store_qw(DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block)
 {
   hipLaunchKernelGGL((dcp_cost_store_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool,

@@ -30,6 +30,9 @@ extern "C" int emul_cost(float const *pool, DcpProfileDev const *pf, DcpCodeRow 
   case 802: cost_q<8, 2>(pool, *pf, c, L, xt, out); return 0;
   case 804: cost_q<8, 4>(pool, *pf, c, L, xt, out); return 0;
   case 808: cost_q<8, 8>(pool, *pf, c, L, xt, out); return 0;
+  case 501: cost_q<5, 1>(pool, *pf, c, L, xt, out); return 0; // on the 384-column layout of (6,1)
+  case 701: cost_q<7, 1>(pool, *pf, c, L, xt, out); return 0; // on the 512-column layout of (8,1)
+  case 502: cost_q<5, 2>(pool, *pf, c, L, xt, out); return 0; // on the 768-column layout of (6,2)
   case 601: cost_q<6, 1>(pool, *pf, c, L, xt, out); return 0;
   case 602: cost_q<6, 2>(pool, *pf, c, L, xt, out); return 0;
   case 604: cost_q<6, 4>(pool, *pf, c, L, xt, out); return 0;

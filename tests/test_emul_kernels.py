@@ -74,6 +74,32 @@ def test_tie_rich_random_cases(em, orc):
         assert np.array_equal(xn, xo) and np.array_equal(nd, no), (it, K, quant)
 
 
+def test_one_position_per_lane_less_on_the_class_layout(em, orc):
+    """dcp_launch_cost_narrow: K <= 320 / 448 / 640 run as (5,1) / (7,1) / (5,2) on the tables padded for
+    (6,1) / (8,1) / (6,2) -- the same bits as the oracle (and therefore as the class's own shape)."""
+    rng = np.random.default_rng(21)
+    cases = [(257, 6, 1, 5), (300, 6, 1, 5), (320, 6, 1, 5), (385, 8, 1, 7), (448, 8, 1, 7), (513, 6, 2, 5), (640, 6, 2, 5)]
+    for it, (K, Q, W, QA) in enumerate(cases * 2):
+        quant = [None, 2.0][it % 2]
+        prof = synth_profile(rng, K, quant, [0, 0.05][it % 2])
+        if it >= len(cases):  # cheap delete runs: the lazy loop carries across lanes (and waves)
+            prof.trans[7, 1:] = np.float32(0.01)
+            prof.trans[3, 1:] = np.float32(0.02)
+        seq = random_seq(rng, int(rng.integers(20, 70)))
+        xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+        if quant:
+            xt = (np.round(xt / quant) * quant).astype(np.float32)
+        pool, pd = pack_profile(prof, Q, W)
+        pd.Q = QA
+        rows = code_rows(seq)
+        xt16 = np.zeros(16, np.float32)
+        xt16[:13] = xt
+        out = np.zeros(2, np.float32)
+        assert em.emul_cost(_vp(pool), C.byref(pd), _vp(rows), len(seq), _vp(xt16), _vp(out)) == 0
+        assert bits(out[0]) == bits(orc.null(prof, xt, seq)), (K, QA)
+        assert bits(out[1]) == bits(orc.cost(prof, xt, seq)), (K, QA)
+
+
 def test_long_delete_runs_cross_many_lanes(em, orc):
     """Cheap D->D and expensive everything else: delete runs span dozens of lanes, so the
     lazy carry loop must iterate many times (worst case of c-core/viterbi.c:569-580)."""

@@ -139,6 +139,36 @@ def test_products_tsv_of_the_reference(engine, orc):
         assert got == want
 
 
+def test_one_position_per_lane_less_than_the_class_layout(engine, orc, monkeypatch):
+    """K <= 320 / 448 / 640 run (5,1) / (7,1) / (5,2) on the tables of (6,1) / (8,1) / (6,2)
+    (dcp_launch_cost_narrow): the oracle's bits, and the bits of the class's own shape (DECIPHON_HIP_NARROW=0)."""
+    rng = np.random.default_rng(404)
+    Ks = (257, 300, 320, 321, 384, 385, 448, 449, 512, 513, 600, 640, 641, 768)
+    profs = [synth_profile(rng, K, [None, 2.0][i % 2], [0.0, 0.05][i % 2]) for i, K in enumerate(Ks)]
+    for p in profs[::3]:  # cheap delete runs: carries across lanes and across the two wavefronts
+        p.trans[7, 1:] = np.float32(0.01)
+        p.trans[3, 1:] = np.float32(0.02)
+    engine.clear_profiles()
+    for p in profs:
+        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+    engine.commit()
+    reads = [random_seq(rng, n) for n in (3, 40, 181, 400)]
+    engine.set_sequences(reads)
+    engine.set_mode(True, False)
+    wins = [(pi, si, 0, len(r)) for pi in range(len(profs)) for si, r in enumerate(reads)]
+    monkeypatch.delenv("DECIPHON_HIP_NARROW", raising=False)
+    nul, alt = engine.cost(wins)
+    monkeypatch.setenv("DECIPHON_HIP_NARROW", "0")
+    nul0, alt0 = engine.cost(wins)
+    monkeypatch.delenv("DECIPHON_HIP_NARROW")
+    assert np.array_equal(nul.view(np.uint32), nul0.view(np.uint32))
+    assert np.array_equal(alt.view(np.uint32), alt0.view(np.uint32))
+    for i, (pi, si, a, b) in enumerate(wins):
+        xt = orc.xtrans(max((b - a) // 3, 1), True, False)
+        assert bits(nul[i]) == bits(orc.null(profs[pi], xt, reads[si])), wins[i]
+        assert bits(alt[i]) == bits(orc.cost(profs[pi], xt, reads[si])), wins[i]
+
+
 def test_windows_inside_reads_and_ragged_batch(engine, orc):
     """Windows that start mid-read (the t-mers before the window start must not leak in),
     lengths 1..5 (fewer than five emission lengths), and profiles of every Q class in one call."""
