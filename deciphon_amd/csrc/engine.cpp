@@ -489,6 +489,10 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
   for (int c = 4; narrow && c < DCP_NUM_CLASSES; ++c) kernels += st.c_wide[c] > st.c_begin[c];
   bool const fork = kernels > 1;
   if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
+  // x->stream joins the kernels only after the last launch: a wait is a barrier in x->stream's hardware queue,
+  // and a stream that shares that queue would start its kernel behind every barrier issued before
+  // (profiles/r02_step_timeline.txt)
+  std::vector<hipEvent_t> joins;
   // Launch order = start order (the hardware runs a few queues side by side and takes kernels as they come):
   // the classes with the fewest, longest-running workgroups go first -- multi-wave groups, then 8, 6, 4, 3
   // positions per lane -- and the packed kernels with their many short wavefronts last, where they fill what
@@ -519,7 +523,7 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
       if (fork)
       {
         HIP_TRY(x, hipEventRecord(x->njoin_ev[c], n.stream), DCP_EFUNCUSE);
-        HIP_TRY(x, hipStreamWaitEvent(x->stream, x->njoin_ev[c], 0), DCP_EFUNCUSE);
+        joins.push_back(x->njoin_ev[c]);
       }
       b.problems += nn;
       b.nprob -= nn;
@@ -528,7 +532,7 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
     if (fork)
     {
       HIP_TRY(x, hipEventRecord(x->join_ev[c], b.stream), DCP_EFUNCUSE);
-      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
+      joins.push_back(x->join_ev[c]);
     }
   }
   if (fused)
@@ -544,7 +548,7 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
     if (fork)
     {
       HIP_TRY(x, hipEventRecord(x->join_ev[0], a.stream), DCP_EFUNCUSE);
-      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[0], 0), DCP_EFUNCUSE);
+      joins.push_back(x->join_ev[0]);
     }
   }
   for (int s = DCP_NUM_PACK_SHAPES - 1; s >= 0; --s)
@@ -567,9 +571,10 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
     if (fork)
     {
       HIP_TRY(x, hipEventRecord(x->pjoin_ev[s], a.stream), DCP_EFUNCUSE);
-      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->pjoin_ev[s], 0), DCP_EFUNCUSE);
+      joins.push_back(x->pjoin_ev[s]);
     }
   }
+  for (hipEvent_t ev : joins) HIP_TRY(x, hipStreamWaitEvent(x->stream, ev, 0), DCP_EFUNCUSE);
   return 0;
 }
 
