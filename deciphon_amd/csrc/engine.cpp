@@ -451,6 +451,7 @@ int launch_all(dcp_hip *x, Staged const &st, bool path)
   for (int c = 0; c < DCP_NUM_CLASSES; ++c) classes += st.c_begin[c + 1] > st.c_begin[c];
   bool const fork = classes > 1;
   if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
+  std::vector<hipEvent_t> joins; // joined after the last launch (see launch_cost_all)
   for (int c = 0; c < DCP_NUM_CLASSES; ++c)
   {
     DcpLaunch a = launch_args(x, st, c);
@@ -465,9 +466,10 @@ int launch_all(dcp_hip *x, Staged const &st, bool path)
     if (fork)
     {
       HIP_TRY(x, hipEventRecord(x->join_ev[c], a.stream), DCP_EFUNCUSE);
-      HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
+      joins.push_back(x->join_ev[c]);
     }
   }
+  for (hipEvent_t ev : joins) HIP_TRY(x, hipStreamWaitEvent(x->stream, ev, 0), DCP_EFUNCUSE);
   return 0;
 }
 
@@ -1450,6 +1452,7 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
   bool const fork = classes > 1;
   auto per_class = [&](auto &&launch) -> int {
     if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
+    std::vector<hipEvent_t> joins; // joined after the last launch (see launch_cost_all)
     for (int c = 0; c < DCP_NUM_CLASSES; ++c)
     {
       DcpLaunch a = launch_args(x, st, c);
@@ -1464,9 +1467,10 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
       if (fork)
       {
         HIP_TRY(x, hipEventRecord(x->join_ev[c], a.stream), DCP_EFUNCUSE);
-        HIP_TRY(x, hipStreamWaitEvent(x->stream, x->join_ev[c], 0), DCP_EFUNCUSE);
+        joins.push_back(x->join_ev[c]);
       }
     }
+    for (hipEvent_t ev : joins) HIP_TRY(x, hipStreamWaitEvent(x->stream, ev, 0), DCP_EFUNCUSE);
     return 0;
   };
   if (max_blocks > 1) // the checkpoints of the windows that have more than one block
