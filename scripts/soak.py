@@ -19,8 +19,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
 rng = np.random.default_rng(seed)
 orc = oracle()
 eng = deciphon_amd.Engine(0)
-edges = [1, 2, 3, 63, 64, 65, 128, 129, 192, 193, 256, 257, 384, 385, 512, 513, 768, 769, 1024, 1025, 1536, 1537, 2048,
-         2049, 4096, 4097, 6144, 6145, 8192]
+edges = [1, 2, 3, 12, 13, 28, 29, 60, 61, 63, 64, 65, 93, 94, 124, 125, 128, 129, 192, 193, 256, 257, 320, 321, 384, 385, 448,
+         449, 512, 513, 640, 641, 768, 769, 1024, 1025, 1536, 1537, 2048, 2049, 4096, 4097, 6144, 6145, 8192]
 t0 = time.time()
 rounds = windows = redone = 0
 while time.time() - t0 < budget:
