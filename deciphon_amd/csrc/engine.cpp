@@ -37,12 +37,21 @@ template <class T> struct DevBuf
 {
   T *p = nullptr;
   size_t cap = 0; // elements
+  bool borrowed = false; // the memory belongs to another engine (dcp_hip_view_refresh)
   ~DevBuf() { release(); }
   void release()
   {
-    if (p) (void)hipFree(p);
+    if (p && !borrowed) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    borrowed = false;
+  }
+  void borrow(DevBuf const &o)
+  {
+    release();
+    p = o.p;
+    cap = o.cap;
+    borrowed = o.p != nullptr;
   }
   hipError_t reserve(size_t n)
   {
@@ -626,6 +635,39 @@ struct dcp_hip *dcp_hip_new(int device)
   x->seq_off.assign(1, 0);
   x->row_off.assign(1, 0);
   return x;
+}
+
+// A second engine over the SAME database and reads (dcp_scan_run: the path pass of one round of windows runs on
+// it, from a host thread of its own, while the first engine runs the cost pass of the next round): the view
+// borrows the parent's profile pool, descriptors, code rows and mode, and has its own streams, problem lists,
+// DP tables and results.  Call again after anything of that changed on the parent; the parent must outlive the view.
+int dcp_hip_view_refresh(struct dcp_hip *view, struct dcp_hip const *parent)
+{
+  if (!view || !parent || view == parent || view->device != parent->device) return DCP_EFUNCUSE;
+  HIP_TRY(view, hipSetDevice(view->device), DCP_EFUNCUSE);
+  HIP_TRY(view, hipStreamSynchronize(view->stream), DCP_EFUNCUSE);
+  view->profiles = parent->profiles;
+  view->committed = parent->committed;
+  view->pool_used = parent->pool_used;
+  view->d_pool.borrow(parent->d_pool);
+  view->d_profiles.borrow(parent->d_profiles);
+  view->seq_off = parent->seq_off;
+  view->row_off = parent->row_off;
+  view->d_nt.borrow(parent->d_nt);
+  view->d_seq_off.borrow(parent->d_seq_off);
+  view->d_row_off.borrow(parent->d_row_off);
+  view->d_rows.borrow(parent->d_rows);
+  if (view->mode_set && (view->multi_hits != parent->multi_hits || view->hmmer3_compat != parent->hmmer3_compat)) view->xt_rows = 0;
+  view->mode_set = parent->mode_set;
+  view->multi_hits = parent->multi_hits;
+  view->hmmer3_compat = parent->hmmer3_compat;
+  if (view->xt_override != parent->xt_override)
+  {
+    view->xt_override = parent->xt_override;
+    view->xt_rows = 0;
+  }
+  view->staged_n = -1;
+  return 0;
 }
 
 void dcp_hip_del(struct dcp_hip *x)

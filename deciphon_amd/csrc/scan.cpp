@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <deque>
+#include <future>
 #include <memory>
 #include <string>
 #include <sys/stat.h>
@@ -49,6 +50,7 @@ struct dcp_batch
 struct dcp_scan
 {
   dcp_hip *eng = nullptr;
+  dcp_hip *eng_path = nullptr; // a view of eng (dcp_hip_view_refresh): the path passes, overlapped with the cost passes
   int device = 0;
   bool multi_hits = true, hmmer3_compat = false;
   void (*callback)(void *) = nullptr;
@@ -246,16 +248,20 @@ int setup_common(dcp_scan *x, char const *dbfile, int device, int index, int npa
   x->db.reset(new DcpDbReader);
   if ((rc = x->db->open(dbfile))) return raise(rc, __func__, dbfile);
   x->decoders.clear();
+  if (x->eng_path) dcp_hip_del(x->eng_path); // the view first: it borrows the other's tables
+  x->eng_path = nullptr;
   if (x->eng) dcp_hip_del(x->eng);
   x->eng = dcp_hip_new(device);
   if (!x->eng) return raise(DCP_EFUNCUSE, __func__, "no usable HIP device (there is no CPU fallback)");
+  x->eng_path = dcp_hip_new(device);
+  if (!x->eng_path) return raise(DCP_EFUNCUSE, __func__, "no second engine for the path passes");
   x->device = device;
   {
     // HBM for the path pass's DP tables, first: VRAM is cleared on allocation, in the background,
     // and the clearing then overlaps the database load and the first cost pass.  Best effort:
     // dcp_hip_path allocates what it needs anyway.
     char const *mb = getenv("DECIPHON_HIP_PATH_BUDGET_MB");
-    (void)dcp_hip_path_reserve(x->eng, mb ? (int64_t)std::max(atol(mb), 1L) << 20 : (int64_t)4 << 30);
+    (void)dcp_hip_path_reserve(x->eng_path, mb ? (int64_t)std::max(atol(mb), 1L) << 20 : (int64_t)4 << 30);
   }
   if (x->num_proteins > 0)
   {
@@ -283,6 +289,7 @@ void dcp_scan_del(struct dcp_scan const *cx)
 {
   dcp_scan *x = const_cast<dcp_scan *>(cx);
   if (!x) return;
+  if (x->eng_path) dcp_hip_del(x->eng_path);
   if (x->eng) dcp_hip_del(x->eng);
   delete x;
 }
@@ -340,6 +347,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   for (int i = 0; i < nseq; ++i)
     memcpy(nt.data() + off[(size_t)i], batch->seqs[(size_t)i].nt.data(), batch->seqs[(size_t)i].nt.size());
   if ((rc = dcp_hip_set_sequences(x->eng, nseq, nt.data(), off.data()))) return raise(rc, __func__, dcp_hip_strerror(x->eng));
+  if ((rc = dcp_hip_view_refresh(x->eng_path, x->eng))) return raise(rc, __func__, dcp_hip_strerror(x->eng_path));
 
   // product_open (c-core/product.c:14-32)
   std::string const dir = product_dir;
@@ -385,6 +393,85 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
       for (int s = 0; s < nseq; ++s)
         if (!batch->seqs[(size_t)s].nt.empty())
           pairs.emplace_back(p, s, (int)batch->seqs[(size_t)s].nt.size(), dcp_hip_profile_core_size(x->eng, p));
+    // Rounds.  A round is the next window of every pair that is not waiting for a path pass: cost pass + LRT filter
+    // on x->eng (c-core/thread.c:114-121), then the path pass of the round's hits on x->eng_path, from a thread of
+    // its own, WHILE the next round's cost pass runs -- a pair with a hit sits that round out (its next window
+    // starts from the hit, c-core/thread.c:162) and rejoins the one after.  Pairs are independent and the rows are
+    // sorted at the end, so products.tsv does not change.  DECIPHON_HIP_OVERLAP=0: one after the other.
+    struct Pending
+    {
+      std::vector<dcp_hip_window> hits;
+      std::vector<size_t> pair_of;
+      std::vector<float> lrts;
+      std::future<int> done;
+    };
+    std::unique_ptr<Pending> pending;
+    char const *overlap_env = getenv("DECIPHON_HIP_OVERLAP");
+    bool const overlap = !(overlap_env && overlap_env[0] == '0');
+    std::vector<char> waiting(pairs.size(), 0);
+    // the finished path pass: hit spans first (they move the window chains); the rows are then formatted by up to
+    // 16 host threads (a row is a few thousand short appends) while the next rounds run on the GPU
+    auto collect = [&](Pending &pd) -> int {
+      int prc = pd.done.get();
+      if (prc) return raise(prc, __func__, dcp_hip_strerror(x->eng_path));
+      ph.path += ph.lap();
+      auto jobs = std::make_shared<std::vector<Job>>();
+      for (size_t h = 0; h < pd.hits.size(); ++h)
+      {
+        waiting[pd.pair_of[h]] = 0;
+        int const n = dcp_hip_path_nsteps(x->eng_path, (int)h);
+        Job j;
+        j.ids.resize((size_t)n);
+        j.sizes.resize((size_t)n);
+        if ((prc = dcp_hip_path_steps(x->eng_path, (int)h, j.ids.data(), j.sizes.data()))) return raise(prc, __func__);
+        if (!dcp_find_hit(j.ids, j.sizes, j.hit)) continue;
+        Pair &pr = pairs[pd.pair_of[h]];
+        pr.win.last_hit_pos = j.hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
+        j.profile = pr.profile;
+        j.seq = pr.seq;
+        j.widx = pr.win.idx;
+        j.wstart = pr.win.start;
+        j.wstop = pr.win.stop;
+        j.lrt = pd.lrts[h];
+        if (!x->decoders[(size_t)pr.profile]) // decoder_setup, c-core/decoder.c:21-36
+        {
+          auto dec = std::make_shared<DcpDecoder>();
+          if ((prc = x->db->read_decoder(x->index_offset + pr.profile, *dec))) return raise(prc, __func__);
+          x->decoders[(size_t)pr.profile] = dec;
+        }
+        j.dec = x->decoders[(size_t)pr.profile];
+        jobs->push_back(std::move(j));
+      }
+      if (!jobs->empty())
+      {
+        formatted.emplace_back(jobs->size());
+        std::vector<Row> *out = &formatted.back();
+        dcp_scan const *scan = x;
+        std::atomic<int> *drc = &decode_rc;
+        formatters.add(std::thread([jobs, out, scan, batch, drc]() {
+          std::atomic<size_t> next_job{0};
+          auto work = [&]() {
+            for (size_t k = next_job.fetch_add(1); k < jobs->size(); k = next_job.fetch_add(1))
+            {
+              Job const &j = (*jobs)[k];
+              dcp_batch::Seq const &seq = batch->seqs[(size_t)j.seq];
+              (*out)[k] = Row{j.profile, j.seq, j.widx,
+                              format_row(seq, j.widx, j.wstart, j.wstop, j.hit,
+                                         dcp_hip_profile_accession(scan->eng, j.profile), scan->abc_name.c_str(),
+                                         j.lrt, j.ids, j.sizes, *j.dec, drc)};
+            }
+          };
+          unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
+                                                        (unsigned)std::max<size_t>(jobs->size() / 8, 1)});
+          std::vector<std::thread> pool;
+          for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+          work();
+          for (std::thread &t : pool) t.join();
+        }));
+      }
+      ph.rows += ph.lap();
+      return 0;
+    };
     for (;;)
     {
       std::vector<dcp_hip_window> wins;
@@ -392,7 +479,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
       for (size_t i = 0; i < pairs.size(); ++i)
       {
         Pair &pr = pairs[i];
-        if (!pr.active) continue;
+        if (!pr.active || waiting[i]) continue;
         if (!pr.win.next())
         {
           pr.active = false;
@@ -401,96 +488,62 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
         wins.push_back(dcp_hip_window{pr.profile, pr.seq, pr.win.start, pr.win.stop});
         owner.push_back(i);
       }
-      if (wins.empty()) break;
-      ++rounds;
-      nwindows += wins.size();
+      if (wins.empty() && !pending) break;
       ph.windows += ph.lap();
       // c-core/thread.c:114-121: null and alternative scores, lrt and its filter -- all on the device; what comes
       // back are the windows that go on to the path pass
       std::vector<int32_t> hit_index(wins.size());
       std::vector<float> lrts(wins.size());
       int nh = 0;
-      if ((rc = dcp_hip_cost_hits(x->eng, (int)wins.size(), wins.data(), &nh, hit_index.data(), lrts.data())))
-        return raise(rc, __func__, dcp_hip_strerror(x->eng));
-      ph.cost += ph.lap();
-      std::vector<dcp_hip_window> hits((size_t)nh);
-      std::vector<size_t> hit_of((size_t)nh);
-      lrts.resize((size_t)nh);
-      for (int h = 0; h < nh; ++h)
+      if (!wins.empty())
       {
-        hit_of[(size_t)h] = (size_t)hit_index[(size_t)h];
-        hits[(size_t)h] = wins[hit_of[(size_t)h]];
-      }
-      // one path pass per round (the engine slices it by the HBM its DP tables take)
-      for (size_t h0 = 0; h0 < hits.size();)
-      {
-        size_t const h1 = hits.size();
-        nhits += h1 - h0;
-        ph.windows += ph.lap();
-        if ((rc = dcp_hip_path(x->eng, (int)(h1 - h0), hits.data() + h0)))
+        ++rounds;
+        nwindows += wins.size();
+        if ((rc = dcp_hip_cost_hits(x->eng, (int)wins.size(), wins.data(), &nh, hit_index.data(), lrts.data())))
+        {
+          if (pending) (void)pending->done.get();
           return raise(rc, __func__, dcp_hip_strerror(x->eng));
-        ph.path += ph.lap();
-        // hit spans first (they move the window chains); the rows are then formatted by up to 16
-        // host threads (a row is a few thousand short appends) while the next round runs on the GPU
-        auto jobs = std::make_shared<std::vector<Job>>();
-        for (size_t h = h0; h < h1; ++h)
-        {
-          int const n = dcp_hip_path_nsteps(x->eng, (int)(h - h0));
-          Job j;
-          j.ids.resize((size_t)n);
-          j.sizes.resize((size_t)n);
-          if ((rc = dcp_hip_path_steps(x->eng, (int)(h - h0), j.ids.data(), j.sizes.data()))) return raise(rc, __func__);
-          if (!dcp_find_hit(j.ids, j.sizes, j.hit)) continue;
-          Pair &pr = pairs[owner[hit_of[h]]];
-          pr.win.last_hit_pos = j.hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
-          j.profile = pr.profile;
-          j.seq = pr.seq;
-          j.widx = pr.win.idx;
-          j.wstart = pr.win.start;
-          j.wstop = pr.win.stop;
-          j.lrt = lrts[h];
-          if (!x->decoders[(size_t)pr.profile]) // decoder_setup, c-core/decoder.c:21-36
-          {
-            auto dec = std::make_shared<DcpDecoder>();
-            if ((rc = x->db->read_decoder(x->index_offset + pr.profile, *dec))) return raise(rc, __func__);
-            x->decoders[(size_t)pr.profile] = dec;
-          }
-          j.dec = x->decoders[(size_t)pr.profile];
-          jobs->push_back(std::move(j));
         }
-        if (!jobs->empty())
+      }
+      ph.cost += ph.lap();
+      if (pending) // the path pass that ran meanwhile
+      {
+        rc = collect(*pending);
+        pending.reset();
+        if (rc) return rc;
+      }
+      if (nh > 0)
+      {
+        pending.reset(new Pending);
+        pending->hits.resize((size_t)nh);
+        pending->pair_of.resize((size_t)nh);
+        pending->lrts.assign(lrts.begin(), lrts.begin() + nh);
+        for (int h = 0; h < nh; ++h)
         {
-          formatted.emplace_back(jobs->size());
-          std::vector<Row> *out = &formatted.back();
-          dcp_scan const *scan = x;
-          std::atomic<int> *drc = &decode_rc;
-          formatters.add(std::thread([jobs, out, scan, batch, drc]() {
-            std::atomic<size_t> next_job{0};
-            auto work = [&]() {
-              for (size_t k = next_job.fetch_add(1); k < jobs->size(); k = next_job.fetch_add(1))
-              {
-                Job const &j = (*jobs)[k];
-                dcp_batch::Seq const &seq = batch->seqs[(size_t)j.seq];
-                (*out)[k] = Row{j.profile, j.seq, j.widx,
-                                format_row(seq, j.widx, j.wstart, j.wstop, j.hit,
-                                           dcp_hip_profile_accession(scan->eng, j.profile), scan->abc_name.c_str(),
-                                           j.lrt, j.ids, j.sizes, *j.dec, drc)};
-              }
-            };
-            unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
-                                                          (unsigned)std::max<size_t>(jobs->size() / 8, 1)});
-            std::vector<std::thread> pool;
-            for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
-            work();
-            for (std::thread &t : pool) t.join();
-          }));
+          size_t const wi = (size_t)hit_index[(size_t)h];
+          pending->hits[(size_t)h] = wins[wi];
+          pending->pair_of[(size_t)h] = owner[wi];
+          waiting[owner[wi]] = 1;
         }
-        h0 = h1;
-        ph.rows += ph.lap();
+        nhits += (size_t)nh;
+        dcp_hip *const pe = x->eng_path;
+        Pending *const pd = pending.get();
+        pending->done = std::async(overlap ? std::launch::async : std::launch::deferred,
+                                   [pe, pd]() { return dcp_hip_path(pe, (int)pd->hits.size(), pd->hits.data()); });
+        if (!overlap)
+        {
+          rc = collect(*pending);
+          pending.reset();
+          if (rc) return rc;
+        }
       }
       if (x->callback)
         for (size_t i = 0; i < wins.size(); ++i) x->callback(x->userdata); // once per window, c-core/thread.c:74
-      if (x->interrupted) break;
+      if (x->interrupted)
+      {
+        if (pending) (void)pending->done.get();
+        break;
+      }
     }
     x->done_proteins += p1 - p0;
   }
