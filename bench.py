@@ -304,7 +304,14 @@ def main():
             ach = valu / (kernel_ms * 1e-3) / 1e9
             roof.update(achieved=ach, frac=ach / VALU_ISSUE_PEAK, traffic=pmc.get("hbm_bytes_per_step"),
                         valu_insts_per_step=valu, counters_source=pmc_src,
-                        valu_insts_per_cell=valu * 64.0 / cells)
+                        valu_insts_per_cell=valu * 64.0 / cells,
+                        measured_stream_rates={
+                            "unit": "G wave-instr/s", "source": "profiles/r02_valu_rates.txt (scripts/valu_rates.hip)",
+                            "mix_2add_1min3_8_waves_per_simd": 848.0, "mix_3_waves_per_simd": 729.0,
+                            "mix_2_waves_per_simd": 640.0, "v_add_f32_alone": 735.0, "v_min3_f32_alone": 546.0,
+                            "frac_of_mix_at_8_waves": ach / 848.0,
+                            "note": "no instruction stream measured on this GPU issues at the nominal 2 cycles per wave64; "
+                                    "the cost kernels run 2-4 wavefronts per SIMD"})
             if pmc.get("hbm_bytes_per_step"):
                 roof["hbm"]["achieved_GBps"] = pmc["hbm_bytes_per_step"] / (kernel_ms * 1e-3) / 1e9
                 roof["hbm"]["frac"] = roof["hbm"]["achieved_GBps"] / HBM_PEAK_GBPS
