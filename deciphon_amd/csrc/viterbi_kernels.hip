@@ -28,8 +28,16 @@ __device__ __forceinline__ int dcp_xcd_remap(int b, int n)
 
 // (tried: holding Q = 3 / 4 to 96 / 128 VGPRs for 5 / 4 waves per SIMD -- the 6-7 scratch reloads per row cost
 // far more than the occupancy gives: 881 -> 620 GCUPS at K = 173, 1000 -> 878 at K = 256)
+// Wavefronts per SIMD the register allocator must leave room for.  A wavefront issues a VALU every ~7.5 cycles
+// whatever its instruction-level parallelism (profiles/r02_valu_rates.txt), so two wavefronts per SIMD cap the
+// issue rate at 640 G/s and three at 729: (5,1) is held to 168 VGPRs -- what it spills then lies outside the row
+// loop (K = 300: 796 -> 838 GCUPS).  The same bound on (6,1), (7,1) puts 26-55 scratch loads into every row, on
+// (3,1) / (4,1) / the packed kernels 7-10 (slower: profiles/r02_exp_trans_stash_occupancy.txt).
+#ifndef DCP_COST_WAVES
+#define DCP_COST_WAVES(Q, W) ((W) == 1 && (Q) == 5 ? 3 : (Q) >= 8 ? 2 : 1)
+#endif
 template <int Q, int W>
-__global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_kernel(float const *__restrict__ pool,
+__global__ __launch_bounds__(64 * W, DCP_COST_WAVES(Q, W)) void dcp_cost_kernel(float const *__restrict__ pool,
                                                       DcpProfileDev const *__restrict__ profiles,
                                                       DcpProblem const *__restrict__ problems,
                                                       DcpCodeRow const *__restrict__ code_rows,
