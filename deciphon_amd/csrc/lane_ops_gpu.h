@@ -98,6 +98,9 @@ DCP_FN uint32_t wave_minu(lu v)
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// issue priority of this wavefront among those of its SIMD (0..3; s_setprio)
+template <int P> DCP_FN void wave_priority() { __builtin_amdgcn_s_setprio(P); }
+
 DCP_FN bool wave_any(lm m) { return __builtin_amdgcn_ballot_w64(m) != 0ull; }
 DCP_FN uint64_t wave_ballot(lm m) { return __builtin_amdgcn_ballot_w64(m); }
 DCP_FN float read_lane(lf x, int lane)

@@ -128,6 +128,13 @@ template <int Q, int W, bool STORE = false> struct CostWave
   DCP_FN void init(float const *__restrict__ pool, DcpProfileDev const &pf, DcpCodeRow const *__restrict__ code_rows,
                    float const *__restrict__ xt)
   {
+    // Wavefronts with more work per row take longer over the same window: they get the SIMD's issue slots first
+    // (a wavefront alone issues every ~7.5 cycles, so what the others lose they make up once it is done).  On a
+    // launch of one generation of mixed classes -- minifam x 1000 reads -- the classes then end together.
+#ifndef DCP_WAVE_PRIO
+#define DCP_WAVE_PRIO(Q, W) ((W) > 1 || (Q) >= 6 ? 3 : (Q) >= 4 ? 2 : (Q) == 3 ? 1 : 0)
+#endif
+    wave_priority<DCP_WAVE_PRIO(Q, W)>();
     g.init();
     lu const lane = g.lane;
     int const Kp = pf.Kp;

@@ -77,6 +77,7 @@ inline bool wave_any(lm m)
   EM_FOR if (m.v[i_]) { ++em_votes_true; return true; }
   return false;
 }
+template <int P> inline void wave_priority() {}
 inline uint64_t wave_ballot(lm m) { uint64_t b = 0; EM_FOR if (m.v[i_]) b |= 1ull << i_; return b; }
 inline float read_lane(lf x, int lane) { return x.v[lane]; }
 inline uint32_t read_laneu(lu x, int lane) { return x.v[lane]; }
