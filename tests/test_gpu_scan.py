@@ -78,6 +78,13 @@ def test_sliding_windows_chain_like_test_window(tmp_path, orc):
     want = oracle_scan(orc, read_dcp(DCP), reads, True, False)
     assert rows == want
     assert any(r.split("\t")[1] != "0" for r in rows)  # a hit in a later window
+    # the same with the path pass of a round run AFTER its cost pass instead of beside the next round's
+    # (dcp_scan_run overlaps them on a second engine; a pair with a hit then sits a round out): the same file
+    os.environ["DECIPHON_HIP_OVERLAP"] = "0"
+    try:
+        assert run_scan(str(tmp_path / "serial"), reads) == rows
+    finally:
+        del os.environ["DECIPHON_HIP_OVERLAP"]
 
 
 def test_long_reads_with_error_bearing_domains_like_config5(tmp_path, orc):
