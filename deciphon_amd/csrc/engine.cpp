@@ -1521,26 +1521,40 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
         })))
       return rc;
   tm.lap("checkpoints");
-  for (int block = max_blocks - 1; block >= 0; --block)
+  // Blocks from the last to the first.  Every class walks its blocks on its own stream -- the rows of a block, then
+  // the traceback through it -- without waiting for the others: a class's windows are done when ITS slowest is,
+  // and the store kernel of one class runs beside the traceback of another (one join at the end).
   {
-    if ((rc = per_class([&](int c, DcpLaunch const &a) {
-          if (c == DCP_STRIP_CLASS) return block == 0 ? dcp_launch_cost_store(c, a, nullptr, 0, 0) : hipSuccess;
-          return dcp_launch_cost_store(c, a, x->d_ckpt_addr.p, B, block);
-        })))
-      return rc;
-    if (strip && block == 0) // their tables hold the whole window: one traceback call, as one block
-    {
-      DcpLaunch a = launch_args(x, st, DCP_STRIP_CLASS);
-      a.arena = nullptr;
-      HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, 0, 0), DCP_EFUNCUSE);
-    }
-    for (int c = 0; c < DCP_STRIP_CLASS; ++c)
+    if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
+    std::vector<hipEvent_t> joins;
+    for (int c = 0; c < DCP_NUM_CLASSES; ++c)
     {
       DcpLaunch a = launch_args(x, st, c);
       if (a.nprob <= 0) continue;
-      a.arena = nullptr;
-      HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, B, block), DCP_EFUNCUSE);
+      a.arena = nullptr; // DcpProblem::trellis holds the table's address
+      if (fork)
+      {
+        a.stream = x->qstream[c];
+        HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
+      }
+      if (c == DCP_STRIP_CLASS) // their tables hold the whole window: one block
+      {
+        HIP_TRY(x, dcp_launch_cost_store(c, a, nullptr, 0, 0), DCP_EFUNCUSE);
+        HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, 0, 0), DCP_EFUNCUSE);
+      }
+      else
+        for (int block = max_blocks - 1; block >= 0; --block)
+        {
+          HIP_TRY(x, dcp_launch_cost_store(c, a, x->d_ckpt_addr.p, B, block), DCP_EFUNCUSE);
+          HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, B, block), DCP_EFUNCUSE);
+        }
+      if (fork)
+      {
+        HIP_TRY(x, hipEventRecord(x->join_ev[c], a.stream), DCP_EFUNCUSE);
+        joins.push_back(x->join_ev[c]);
+      }
     }
+    for (hipEvent_t ev : joins) HIP_TRY(x, hipStreamWaitEvent(x->stream, ev, 0), DCP_EFUNCUSE);
   }
   tm.lap("traceback");
   std::vector<float> out(2 * (size_t)n);
