@@ -1463,12 +1463,10 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
   // checkpoints sit behind each window's block table (dcp_hip_path placed fast_bytes per window)
   std::vector<int64_t> ckpt_addr((size_t)n, 0);
   int max_blocks = 1;
-  bool strip = false;
   for (DcpProblem const &p : st.problems)
   {
     HostProfile const &hp = x->profiles[(size_t)p.profile];
-    if (hp.cls == DCP_STRIP_CLASS) strip = true; // whole tables (dcp_hip_path placed table_bytes for them)
-    else
+    if (hp.cls != DCP_STRIP_CLASS) // (the strip class keeps whole tables: dcp_hip_path placed table_bytes for it)
     {
       ckpt_addr[(size_t)p.out] = p.trellis + (int64_t)((block_table_bytes(p.L, hp.Kp, B) + 15) & ~(size_t)15);
       max_blocks = std::max(max_blocks, dcp_num_blocks(p.L, B));
@@ -1492,38 +1490,10 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
   int classes = 0;
   for (int c = 0; c < DCP_NUM_CLASSES; ++c) classes += st.c_begin[c + 1] > st.c_begin[c];
   bool const fork = classes > 1;
-  auto per_class = [&](auto &&launch) -> int {
-    if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
-    std::vector<hipEvent_t> joins; // joined after the last launch (see launch_cost_all)
-    for (int c = 0; c < DCP_NUM_CLASSES; ++c)
-    {
-      DcpLaunch a = launch_args(x, st, c);
-      if (a.nprob <= 0) continue;
-      a.arena = nullptr; // DcpProblem::trellis holds the table's address
-      if (fork)
-      {
-        a.stream = x->qstream[c];
-        HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
-      }
-      HIP_TRY(x, launch(c, a), DCP_EFUNCUSE);
-      if (fork)
-      {
-        HIP_TRY(x, hipEventRecord(x->join_ev[c], a.stream), DCP_EFUNCUSE);
-        joins.push_back(x->join_ev[c]);
-      }
-    }
-    for (hipEvent_t ev : joins) HIP_TRY(x, hipStreamWaitEvent(x->stream, ev, 0), DCP_EFUNCUSE);
-    return 0;
-  };
-  if (max_blocks > 1) // the checkpoints of the windows that have more than one block
-    if ((rc = per_class([&](int c, DcpLaunch const &a) {
-          return c == DCP_STRIP_CLASS ? hipSuccess : dcp_launch_cost_ckpt(c, a, x->d_ckpt_addr.p, B);
-        })))
-      return rc;
-  tm.lap("checkpoints");
-  // Blocks from the last to the first.  Every class walks its blocks on its own stream -- the rows of a block, then
-  // the traceback through it -- without waiting for the others: a class's windows are done when ITS slowest is,
-  // and the store kernel of one class runs beside the traceback of another (one join at the end).
+  // The checkpoints of the windows that have more than one block, then the blocks from the last to the first.
+  // Every class does that on its own stream -- checkpoints, then per block its rows and the traceback through it --
+  // without waiting for the others: a class's windows are done when ITS slowest is, and the store kernel of one
+  // class runs beside the traceback of another (one join at the end).
   {
     if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
     std::vector<hipEvent_t> joins;
@@ -1543,11 +1513,14 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
         HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, 0, 0), DCP_EFUNCUSE);
       }
       else
+      {
+        if (max_blocks > 1) HIP_TRY(x, dcp_launch_cost_ckpt(c, a, x->d_ckpt_addr.p, B), DCP_EFUNCUSE);
         for (int block = max_blocks - 1; block >= 0; --block)
         {
           HIP_TRY(x, dcp_launch_cost_store(c, a, x->d_ckpt_addr.p, B, block), DCP_EFUNCUSE);
           HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, B, block), DCP_EFUNCUSE);
         }
+      }
       if (fork)
       {
         HIP_TRY(x, hipEventRecord(x->join_ev[c], a.stream), DCP_EFUNCUSE);
