@@ -1,8 +1,10 @@
 // scan.cpp -- the reference's outer API (include/deciphon.h) on top of the engine.
 //
 // Replaces c-core/scan.c (orchestration), thread.c (thread_run / process_window),
-// workload.c / work.c (profile iteration), batch.c (reads) and the products.tsv
-// writer (product.c, product_thread.c), minus HMMER and codon decoding.
+// workload.c / work.c (profile iteration), batch.c (reads), the products.tsv
+// writer (product.c, product_thread.c) and the quasi-codon decoding of the match
+// column (decoder.c, match.c: host_logic.cpp dcp_decode_codon_prob), minus HMMER
+// (the evalue column is "nan" and HMMER's row filter does not run).
 //
 // The reference walks profile-major: for each profile, for each read, for each
 // window -- one DP at a time per thread.  Windows of ONE (profile, read) pair form

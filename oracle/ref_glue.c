@@ -3,6 +3,10 @@
  * Flat-array driver around the REFERENCE's own DP engine.  oracle/Makefile
  * compiles c-core/viterbi.c (+ error.c, loglevel.c) unmodified, straight from
  * /root/reference, and links them with this file into oracle/_ref/libdcp_ref.so.
+ * The same library carries, equally unmodified, the other files of the path
+ * that need only libc and the reference's own headers -- partition_size.c,
+ * state.c (+ bug.c), disambiguate.c, uppercase.c -- whose functions the tests
+ * call directly (tests/test_reference_pins.py).
  * Nothing of the reference is copied into this repository.
  *
  * c-core/trellis.c is NOT compiled: it includes the third-party imm_path.h,
