@@ -948,6 +948,8 @@ int dcp_hip_num_profiles(struct dcp_hip const *x) { return x ? (int)x->profiles.
 
 int dcp_hip_load_chunks(struct dcp_hip const *x) { return x ? x->load_chunks : 0; }
 
+int64_t dcp_hip_pool_bytes(struct dcp_hip const *x) { return x ? (int64_t)(x->pool_used * sizeof(float)) : 0; }
+
 int dcp_hip_profile_core_size(struct dcp_hip const *x, int i)
 {
   if (!x || i < 0 || i >= (int)x->profiles.size()) return -1;
@@ -1238,6 +1240,8 @@ int dcp_hip_fetch_staged(struct dcp_hip *x, float *null_cost, float *alt_cost)
   }
   return 0;
 }
+
+} // extern "C"
 
 namespace
 {
@@ -1578,6 +1582,8 @@ size_t path_budget(dcp_hip *x)
 }
 
 } // namespace
+
+extern "C" {
 
 int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
 {

@@ -63,6 +63,7 @@ struct dcp_scan
   int index_offset = 0;   // global index of local profile 0 (workload_index, c-core/workload.c:95)
   std::string abc_name = "dna";
   std::vector<std::string> products;
+  double timing[DCP_SCAN_TIMING_VALUES] = {0}; // dcp_scan_last_timing
   // quasi-codon decoding (c-core/decoder.c): the database stays mapped, and the distributions of a profile are
   // read from it the first time one of its windows yields a hit
   std::unique_ptr<DcpDbReader> db;
@@ -106,8 +107,9 @@ int mkdir_p(std::string const &dir)
 // DECIPHON_HIP_TIMING=1: phase times of dcp_scan_run on stderr
 struct Phase
 {
-  double windows = 0, cost = 0, path = 0, rows = 0, write = 0;
-  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  double reads = 0, windows = 0, cost = 0, path = 0, rows = 0, write = 0;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), t = t0;
+  double total() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   double lap()
   {
     auto n = std::chrono::steady_clock::now();
@@ -335,6 +337,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   x->interrupted = false;
   x->products.clear();
   int rc = 0;
+  Phase ph;
 
   // batch_encode (c-core/batch.c:60-70): every read goes to HBM once
   int const nseq = (int)batch->seqs.size();
@@ -380,7 +383,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     }
     ~Joiner() { join(); }
   } formatters;
-  Phase ph;
+  ph.reads += ph.lap();
   int rounds = 0;
   size_t nwindows = 0, nhits = 0;
   int const nprof = dcp_hip_num_profiles(x->eng);
@@ -574,6 +577,11 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   }
   if (fclose(fp) != 0 || !ok) return raise(DCP_EWRITEPROD, __func__, file.c_str());
   ph.write += ph.lap();
+  {
+    double const t[DCP_SCAN_TIMING_VALUES] = {ph.total(), ph.reads, ph.windows, ph.cost, ph.path, ph.rows, ph.write,
+                                              (double)rounds, (double)nwindows, (double)nhits};
+    memcpy(x->timing, t, sizeof t);
+  }
   if (getenv("DECIPHON_HIP_TIMING"))
     fprintf(stderr,
             "dcp_scan_run: %d rounds, %zu windows, %zu path passes; windows %.3f s, cost pass %.3f s, path pass %.3f s, "
@@ -594,6 +602,13 @@ int dcp_scan_progress(struct dcp_scan const *x)
 }
 
 long dcp_scan_num_products(struct dcp_scan const *x) { return x ? (long)x->products.size() : 0; }
+
+int dcp_scan_last_timing(struct dcp_scan const *x, double *out, int n)
+{
+  if (!x || (n > 0 && !out)) return 0;
+  for (int i = 0; i < n && i < DCP_SCAN_TIMING_VALUES; ++i) out[i] = x->timing[i];
+  return DCP_SCAN_TIMING_VALUES;
+}
 
 char const *dcp_scan_product(struct dcp_scan const *x, long i)
 {

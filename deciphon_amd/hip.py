@@ -57,6 +57,8 @@ def load_library() -> C.CDLL:
     L.dcp_hip_load_dcp.argtypes = [vp, C.c_char_p, i32, i32]
     L.dcp_hip_num_profiles.argtypes = [vp]
     L.dcp_hip_load_chunks.argtypes = [vp]
+    L.dcp_hip_pool_bytes.argtypes = [vp]
+    L.dcp_hip_pool_bytes.restype = C.c_int64
     L.dcp_hip_profile_core_size.argtypes = [vp, i32]
     L.dcp_hip_profile_accession.argtypes = [vp, i32]
     L.dcp_hip_profile_accession.restype = C.c_char_p
@@ -198,6 +200,11 @@ class Engine:
     def load_chunks(self) -> int:
         """Staging chunks the last load_dcp went through."""
         return self.lib.dcp_hip_load_chunks(self.h)
+
+    @property
+    def pool_bytes(self) -> int:
+        """HBM bytes of the resident profile tables."""
+        return int(self.lib.dcp_hip_pool_bytes(self.h))
 
     @property
     def num_profiles(self) -> int:

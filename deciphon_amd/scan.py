@@ -35,6 +35,7 @@ def _lib():
     L.dcp_scan_num_products.restype = C.c_long
     L.dcp_scan_product.argtypes = [vp, C.c_long]
     L.dcp_scan_product.restype = C.c_char_p
+    L.dcp_scan_last_timing.argtypes = [vp, C.POINTER(C.c_double), i32]
     L.dcp_batch_new.restype = vp
     L.dcp_batch_del.argtypes = [vp]
     L.dcp_batch_del.restype = None
@@ -128,6 +129,15 @@ class Scan:
     def products(self):
         n = self._lib.dcp_scan_num_products(self._cscan)
         return [self._lib.dcp_scan_product(self._cscan, i).decode() for i in range(n)]
+
+    def last_timing(self) -> dict:
+        """Where the wall time of the last run went (dcp_scan_last_timing): seconds per phase and counts."""
+        keys = ("total_s", "reads_h2d_encode_s", "window_bookkeeping_s", "cost_pass_s", "path_pass_s", "rows_decode_s",
+                "products_tsv_s", "rounds", "windows", "path_passes")
+        buf = (C.c_double * len(keys))()
+        n = self._lib.dcp_scan_last_timing(self._cscan, buf, len(keys))
+        assert n == len(keys)
+        return {k: (int(buf[i]) if i >= 7 else float(buf[i])) for i, k in enumerate(keys)}
 
     def interrupt(self):
         self.interrupted = True

@@ -38,23 +38,30 @@ def pfam_like_lengths(n: int, seed: int, lo: int = 10, hi: int = 2500) -> np.nda
 
 def _finish(K, src, seeds, accession):
     """src[K] = (seed protein, node) per position -> a protein dict in protein_unpack's layout."""
+    src = np.asarray(src, np.int64).reshape(K, 2)
+    P, I = src[:, 0], src[:, 1]
     emission = np.empty((K + 1, TABLE_SIZE), np.float32)
     trans = np.empty((K + 1, 7), np.float32)
     BMk = np.empty(K, np.float32)
     nucltp = np.zeros((K + 3, 4), np.float32)    # 0 = null, 1 = background, 2 + n = node n
     codonm = np.zeros((K + 3, 125), np.float32)
-    s0 = seeds[src[0][0]]
+    s0 = seeds[int(P[0])]
     if "nucltp" in s0:
         nucltp[:2], codonm[:2] = s0["nucltp"][:2], s0["codonm"][:2]
-    cons = []
-    for k, (p, i) in enumerate(src):
-        s = seeds[p]
-        emission[k] = s["emission"][i]
-        trans[k] = s["trans"][i]
-        BMk[k] = s["BMk"][i]
+    cons = np.full(K, "x", dtype="<U1")
+    for p, s in enumerate(seeds):  # one gather per seed protein, not one copy per node
+        at = np.nonzero(P == p)[0]
+        if not len(at):
+            continue
+        i = I[at]
+        emission[at] = s["emission"][i]
+        trans[at] = s["trans"][i]
+        BMk[at] = s["BMk"][i]
         if "nucltp" in s:
-            nucltp[2 + k], codonm[2 + k] = s["nucltp"][2 + i], s["codonm"][2 + i]
-        cons.append(s["consensus"][i] if i < len(s["consensus"]) else "x")
+            nucltp[2 + at], codonm[2 + at] = s["nucltp"][2 + i], s["codonm"][2 + i]
+        c = np.array(list(s["consensus"]), dtype="<U1")
+        ok = i < len(c)
+        cons[at[ok]] = c[i[ok]]
     nucltp[2 + K], codonm[2 + K] = nucltp[1 + K], codonm[1 + K]
     # the end of a model as the reference builds it (c-core/model.c; visible in any pressed profile):
     # node K duplicates node K-1, whose MD and DD are impossible and whose DM is certain
@@ -100,13 +107,7 @@ def load_seeds(path: str):
 def pfam_like_database(seeds, n: int, seed: int, first: int = 0, lengths=None):
     """Proteins first..first+n-1 of the (conceptually endless) Pfam-shaped database `seed`: protein i
     depends on (seed, i) only, so partitions can be generated independently of each other."""
-    Ks = pfam_like_lengths(first + n, seed)[first:] if lengths is None else lengths
-    out = []
-    for j, K in enumerate(Ks):
-        i = first + j
-        rng = np.random.default_rng([seed, i])
-        out.append(resample_protein(seeds, int(K), rng, f"SY{i:05d}.1"))
-    return out
+    return list(iter_pfam_like(seeds, n, seed, first, lengths))
 
 
 # ---- reads ---------------------------------------------------------------------------------
@@ -207,18 +208,36 @@ def _f32(a, legacy: bool) -> bytes:
     return _bin(np.ascontiguousarray(a, "<f4").tobytes())
 
 
+def _f32_head(n: int, legacy: bool) -> bytes:
+    """The MessagePack header _f32 puts in front of n floats."""
+    return _f32(np.zeros(n, np.float32), legacy)[: -4 * n]
+
+
 def pack_protein(p: dict, legacy: bool = False) -> bytes:
-    """protein_pack, c-core/protein.c:234-281."""
+    """protein_pack, c-core/protein.c:234-281.  The K + 1 node records all have the same byte layout, so they are
+    laid out as ONE [K + 1][node bytes] array: constant key / header bytes and four float payloads per row."""
     K = int(p["core_size"])
     nucltp = p.get("nucltp", np.zeros((K + 3, 4), np.float32))
     codonm = p.get("codonm", np.zeros((K + 3, 125), np.float32))
+    dt = ">f4" if legacy else "<f4"
 
     def nuclt(j):  # nuclt_dist_pack, c-core/nuclt_dist.c:13-20
         return _arr(2) + _f32(nucltp[j], legacy) + _f32(codonm[j], legacy)
 
-    kn, kt, ke = _s("nuclt_dist"), _s("trans"), _s("emission")
-    nodes = b"".join(kn + nuclt(2 + i) + kt + _f32(p["trans"][i], legacy) + ke + _f32(p["emission"][i], legacy)
-                     for i in range(K + 1))
+    pieces = [(_s("nuclt_dist") + _arr(2) + _f32_head(4, legacy), nucltp[2 : K + 3]),
+              (_f32_head(125, legacy), codonm[2 : K + 3]),
+              (_s("trans") + _f32_head(7, legacy), p["trans"][: K + 1]),
+              (_s("emission") + _f32_head(TABLE_SIZE, legacy), p["emission"][: K + 1])]
+    width = sum(len(h) + 4 * a.shape[1] for h, a in pieces)
+    rec = np.empty((K + 1, width), np.uint8)
+    at = 0
+    for h, a in pieces:
+        rec[:, at : at + len(h)] = np.frombuffer(h, np.uint8)
+        at += len(h)
+        n = 4 * a.shape[1]
+        rec[:, at : at + n] = np.ascontiguousarray(a, dt).view(np.uint8).reshape(K + 1, n)
+        at += n
+    nodes = rec.tobytes()
     return (_map(10) + _s("accession") + _s(p["accession"]) + _s("gencode") + _u(int(p.get("gencode", 1)))
             + _s("consensus") + _s(p["consensus"]) + _s("core_size") + _u(K) + _s("null_nuclt_dist") + nuclt(0)
             + _s("null_emission") + _f32(p["null_emission"], legacy) + _s("bg_nuclt_dist") + nuclt(1)
@@ -226,16 +245,25 @@ def pack_protein(p: dict, legacy: bool = False) -> bytes:
             + _s("BMk") + _f32(p["BMk"], legacy))
 
 
-def write_dcp(path: str, proteins, epsilon: float = 0.01, legacy: bool = False, rna: bool = False) -> None:
-    """proteins: dicts in the layout of deciphon_amd.host.Database.protein (an iterable: each is packed
-    and dropped, so a database larger than memory can be streamed from a generator via a temp list of
-    blobs on disk -- here the blobs are simply kept, the tests stay far below that)."""
-    blobs = [pack_protein(p, legacy) for p in proteins]
+def write_dcp(path: str, proteins, epsilon: float = 0.01, legacy: bool = False, rna: bool = False) -> list:
+    """proteins: an iterable of dicts in the layout of deciphon_amd.host.Database.protein.  Each is packed, appended
+    to a temporary file and dropped (the header, which comes first, needs every record's size), so a database far
+    larger than memory can be streamed from a generator -- as the reference's own writer does with its temporary
+    chunk files (c-core/database_writer.c:14,204-208).  Returns the records' byte sizes."""
+    import os
+    import shutil
+
+    sizes = []
+    body = path + ".proteins.tmp"
+    with open(body, "wb") as f:
+        for p in proteins:
+            b = pack_protein(p, legacy)
+            sizes.append(len(b))
+            f.write(b)
     abc = (_map(4) + _s("symbols") + _s("ACGU" if rna else "ACGT") + _s("idx") + _ext(1, b"\0" * 94)
            + _s("any_symbol_id") + _u(55) + _s("typeid") + _u(5 if rna else 4))
     amino = (_map(4) + _s("symbols") + _s(AMINO) + _s("idx") + _ext(1, b"\0" * 94) + _s("any_symbol_id") + _u(55)
              + _s("typeid") + _u(2))
-    sizes = [len(b) for b in blobs]
     if legacy:
         psz = _ext(6, np.array(sizes, ">u4").tobytes())
     else:
@@ -243,7 +271,18 @@ def write_dcp(path: str, proteins, epsilon: float = 0.01, legacy: bool = False, 
     header = (_map(8) + _s("magic_number") + _u(0xC6F1) + _s("version") + _u(1) + _s("entry_dist") + _u(2)
               + _s("epsilon") + b"\xca" + struct.pack(">f", float(epsilon)) + _s("abc") + abc + _s("amino") + amino
               + _s("has_ga") + b"\xc3" + _s("protein_sizes") + psz)
-    with open(path, "wb") as f:
-        f.write(_map(2) + _s("header") + header + _s("proteins") + _arr(len(blobs)))
-        for b in blobs:
-            f.write(b)
+    try:
+        with open(path, "wb") as f, open(body, "rb") as g:
+            f.write(_map(2) + _s("header") + header + _s("proteins") + _arr(len(sizes)))
+            shutil.copyfileobj(g, f, 64 << 20)
+    finally:
+        os.unlink(body)
+    return sizes
+
+
+def iter_pfam_like(seeds, n: int, seed: int, first: int = 0, lengths=None):
+    """pfam_like_database as a generator: one protein alive at a time."""
+    Ks = pfam_like_lengths(first + n, seed)[first:] if lengths is None else lengths
+    for j, K in enumerate(Ks):
+        i = first + j
+        yield resample_protein(seeds, int(K), np.random.default_rng([seed, i]), f"SY{i:05d}.1")

@@ -157,6 +157,13 @@ int dcp_scan_partition_range(struct dcp_scan const *, int *first, int *count);
 /* Number of product rows the last dcp_scan_run wrote, and row i (without newline). */
 long dcp_scan_num_products(struct dcp_scan const *);
 char const *dcp_scan_product(struct dcp_scan const *, long i);
+/* Where the wall time of the last dcp_scan_run went (measurement only; SURVEY 8d's wall definition: first H2D of the
+ * reads to the last product row on the host).  Fills out[0..n) with, in order: total seconds, reads H2D + encode,
+ * window bookkeeping, cost pass + LRT filter, path pass + unzip (the part the cost pass did not cover), row
+ * formatting + decoding, products.tsv, then the counts of rounds, windows scored and path passes.  Returns how many
+ * values exist (DCP_SCAN_TIMING_VALUES). */
+#define DCP_SCAN_TIMING_VALUES 10
+int dcp_scan_last_timing(struct dcp_scan const *, double *out, int n);
 
 #ifdef __cplusplus
 }

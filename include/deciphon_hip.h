@@ -69,6 +69,8 @@ int dcp_hip_load_dcp(struct dcp_hip *, char const *path, int first, int count);
 /* how many staging chunks the last dcp_hip_load_dcp went through (256 MiB each; DECIPHON_HIP_STAGE_MB
  * shrinks them, never below one profile: a hook for tests of the double-buffered path) */
 int dcp_hip_load_chunks(struct dcp_hip const *);
+/* Bytes of HBM the resident profile tables occupy (rows + transitions, padded). */
+int64_t dcp_hip_pool_bytes(struct dcp_hip const *);
 int dcp_hip_num_profiles(struct dcp_hip const *);
 int dcp_hip_profile_core_size(struct dcp_hip const *, int index);
 char const *dcp_hip_profile_accession(struct dcp_hip const *, int index);
