@@ -112,7 +112,11 @@ struct TableArena
     if (held + want > budget)
     {
       if (placed != 0) return nullptr; // the slice ends here
-      want = bytes;                    // a lone table is tried whatever the budget says
+      // a lone table is tried whatever the budget says -- unless the budget is a hard limit
+      // (DECIPHON_HIP_PATH_STRICT=1: the caller then fails with DCP_ENOMEM, as trellis_setup does when realloc fails)
+      char const *strict = getenv("DECIPHON_HIP_PATH_STRICT");
+      if (strict && strict[0] == '1') return nullptr;
+      want = bytes;
     }
     auto const t0 = std::chrono::steady_clock::now();
     unsigned char *p = nullptr;
@@ -1313,6 +1317,8 @@ int fetch_trellis(dcp_hip *x, int i)
   return 0;
 }
 
+size_t path_budget(dcp_hip *x);
+
 // The literal path pass (viterbi_path as the reference runs it, pass by pass, with the
 // trellis in HBM) + trellis_unzip on the device, for the windows path_wins[idx[..]].
 int path_literal(dcp_hip *x, std::vector<int> const &idx)
@@ -1335,7 +1341,9 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
       std::vector<dcp_hip_window> ws(sl.size());
       x->tables.reset();
       x->table_addr.clear();
-      size_t const room = (size_t)1 << 40; // as much as the device gives: these windows are rare
+      // as much as the device gives (these windows are rare) unless the budget is a hard limit
+      char const *strict = getenv("DECIPHON_HIP_PATH_STRICT");
+      size_t const room = strict && strict[0] == '1' ? path_budget(x) : (size_t)1 << 40;
       for (size_t i = 0; i < sl.size(); ++i)
       {
         dcp_hip_window const &v = w[(size_t)sl[i]];

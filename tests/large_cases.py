@@ -38,6 +38,14 @@ def large_cases():
     return cases
 
 
+def window_cap_cases():
+    """c-core/window.c:13: a window is min(50 K, 100 000) nucleotides, so K >= 2001 and a read of 100 kb or more give
+    windows of 100 000 rows -- the longest DP the scan ever runs.  One multi-wave class (K = 2048) and one strip class
+    (K = 4200), planted domains; idx continues large_cases()' numbering (it seeds the inputs)."""
+    return [dict(idx=100, K=2048, L=100000, kind="tiled", quant=None, pinf=0.0, mh=1, h3=0),
+            dict(idx=101, K=4200, L=100000, kind="tiled", quant=None, pinf=0.0, mh=1, h3=0)]
+
+
 _seeds = None
 
 
@@ -48,6 +56,13 @@ def seeds():
 
         _seeds = load_seeds(os.path.join(GOLDEN, "minifam.dcp"))
     return _seeds
+
+
+def tiled_protein(case) -> dict:
+    """The protein (deciphon_amd.synth layout: what a .dcp holds) behind a "tiled" case."""
+    from deciphon_amd import synth
+
+    return synth.tile_protein(seeds(), case["K"], 37 * case["idx"], f"TILE{case['K']}")
 
 
 def build_case(case, orc):
@@ -61,7 +76,7 @@ def build_case(case, orc):
         prof = synth_profile(rng, K, quant, case["pinf"])
         seq = random_seq(rng, L)
     else:
-        p = synth.tile_protein(seeds(), K, 37 * case["idx"], f"TILE{K}")
+        p = tiled_protein(case)
         prof = orc.setup_profile(Protein(p["accession"], 1, p["consensus"], K, p["null_emission"], p["bg_emission"],
                                          p["trans"], p["emission"], p["BMk"]))
         seq = random_seq(rng, L)

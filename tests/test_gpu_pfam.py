@@ -149,3 +149,61 @@ def test_partitions_concatenate_to_the_whole_scan(pfam, expected, tmp_path, npar
     else:
         # no boundary is further from its target than half the core size next to it
         assert max(owned) - min(owned) <= 2 * max(pfam.Ks)
+
+
+def test_a_database_beyond_4_gb_of_tables(tmp_path, orc):
+    """Pfam-A pressed is ~2e4 profiles, ~20 GB of tables (c-core/database_writer.c:14,204-208 plans for files beyond
+    4 GB).  Here: 4200 Pfam-shaped profiles streamed into a .dcp of ~4.6 GB, ingested through ~20 staging chunks into
+    a pool beyond 2^32 bytes (table offsets past 32 bits), then every window of two 3 kb reads against ALL profiles in
+    one launch; the scores of windows at the first, the last and evenly spread profiles in between -- and the path of
+    a planted domain of the LAST profile, whose tables sit at the far end of the pool -- against the oracle."""
+    from types import SimpleNamespace
+
+    import deciphon_amd
+    from deciphon_amd import synth
+
+    nprof, seed = 4200, 4242
+    seeds = synth.load_seeds(os.path.join(GOLDEN, "minifam.dcp"))
+    Ks = synth.pfam_like_lengths(nprof, seed)
+    dcp = str(tmp_path / "big.dcp")
+    synth.write_dcp(dcp, synth.iter_pfam_like(seeds, nprof, seed, lengths=Ks), 0.01, False, False)
+    assert os.path.getsize(dcp) > 4.0e9
+
+    def protein(i):
+        return synth.pfam_like_database(seeds, 1, seed, first=i, lengths=Ks[i : i + 1])[0]
+
+    rng = np.random.default_rng(8)
+    reads = [rng.integers(0, 4, size=3000).astype(np.uint8) for _ in range(2)]
+    last = protein(nprof - 1)
+    dom = synth.mutate(synth.back_translate(last["consensus"][:200]), rng, 0.05, 0.02, 0.02)[:2000]
+    reads[1][400 : 400 + len(dom)] = dom
+    with deciphon_amd.Engine(0) as eng:
+        eng.load_dcp(dcp)
+        eng.commit()
+        os.unlink(dcp)
+        assert eng.num_profiles == nprof and eng.pool_bytes > 2**32 and eng.load_chunks >= 15
+        assert [eng.core_size(i) for i in (0, nprof // 2, nprof - 1)] == [int(Ks[i]) for i in (0, nprof // 2, nprof - 1)]
+        eng.set_sequences(reads)
+        eng.set_mode(True, False)
+        wins = np.array([(p, r, 0, min(3000, 50 * int(Ks[p]))) for p in range(nprof) for r in range(2)], np.int32)
+        nul, alt = eng.cost(wins)
+        picks = sorted({0, 1, nprof - 2, nprof - 1} | {int(v) for v in np.linspace(0, nprof - 1, 24)})
+        for p in picks:
+            prof = orc.setup_profile(SimpleNamespace(**protein(p)))
+            for r in range(2):
+                i = 2 * p + r
+                seq = np.ascontiguousarray(reads[r][: wins[i][3]])
+                xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+                assert bits(nul[i]) == bits(orc.null(prof, xt, seq)), (p, r)
+                assert bits(alt[i]) == bits(orc.cost(prof, xt, seq)), (p, r)
+        # the planted domain: a hit of the last profile, path and all
+        i = 2 * (nprof - 1) + 1
+        assert -2.0 * ((-nul[i]) - (-alt[i])) > 0
+        prof = orc.setup_profile(SimpleNamespace(**last))
+        seq = np.ascontiguousarray(reads[1][: wins[i][3]])
+        xt = orc.xtrans(max(len(seq) // 3, 1), True, False)
+        _, xn, nd = orc.path(prof, xt, seq)
+        ids, sizes = orc.unzip(prof.K, len(seq), xn, nd)
+        got = eng.path([tuple(int(v) for v in wins[i])], trellis=True)[0]
+        assert np.array_equal(got["state_ids"], ids) and np.array_equal(got["seqsizes"], sizes)
+        assert np.array_equal(got["xnodes"], xn) and np.array_equal(got["nodes"], nd)

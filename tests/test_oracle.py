@@ -145,6 +145,29 @@ def test_long_profile_goldens(orc):
     assert kinds >= {0, 1, 2, 3, 4, 5, 6, 7, 8, 9}  # M, I, D and S, N, B, E, J, C, T all occur on the paths
 
 
+def test_window_cap_golden(orc):
+    """c-core/window.c:13's longest window, 100 000 rows, at K = 2048: the restatement against the reference
+    viterbi.c's bits (tests/golden/window_cap.npz) -- scores, CRC32 of the 410 MB trellis, the unzipped path, the
+    path re-priced.  The strip-class case of the same file (K = 4200, twice the cells) reproduces too (checked when
+    the golden was made: 85 s of this scalar code); it is left to the -m gpu tests, which compare the HIP path
+    with the reference bits directly."""
+    from large_cases import build_case, path_cost, window_cap_cases
+
+    g = np.load(os.path.join(GOLDEN, "window_cap.npz"))
+    c = window_cap_cases()[0]
+    assert (c["K"], c["L"]) == (int(g["K"][0]), int(g["L"][0])) == (2048, 100000)
+    prof, seq, xt = build_case(c, orc)
+    assert bits(orc.null(prof, xt, seq)) == int(g["null_bits"][0])
+    alt, xn, nd = orc.path(prof, xt, seq)
+    assert bits(alt) == int(g["alt_bits"][0])
+    assert zlib.crc32(xn.tobytes()) == int(g["xnodes_crc"][0]) and zlib.crc32(nd.tobytes()) == int(g["nodes_crc"][0])
+    ids, sizes = orc.unzip(prof.K, len(seq), xn, nd)
+    a, b = int(g["path_off"][0]), int(g["path_off"][1])
+    assert np.array_equal(ids, g["path_ids"][a:b]) and np.array_equal(sizes, g["path_sizes"][a:b])
+    total = path_cost(orc, prof, xt, seq, ids, sizes)
+    assert abs(total - float(alt)) <= 1e-4 * abs(float(alt))
+
+
 def test_products_tsv_golden(orc, minifam, reads):
     """The reference's committed scan result (control/tests/files/snap.dcs): windows, hit
     spans, lrt as printed, and the (subsequence, state) pairs of the match column."""
