@@ -1507,6 +1507,8 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
   // without waiting for the others: a class's windows are done when ITS slowest is, and the store kernel of one
   // class runs beside the traceback of another (one join at the end).
   {
+    char const *fused_env = getenv("DECIPHON_HIP_PATH_FUSED");
+    bool const fused = !(fused_env && fused_env[0] == '0');
     if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
     std::vector<hipEvent_t> joins;
     for (int c = 0; c < DCP_NUM_CLASSES; ++c)
@@ -1524,7 +1526,10 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
         HIP_TRY(x, dcp_launch_cost_store(c, a, nullptr, 0, 0), DCP_EFUNCUSE);
         HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, 0, 0), DCP_EFUNCUSE);
       }
-      else
+      else if (fused) // one launch: every window walks its own blocks (dcp_path_blocks_kernel)
+        HIP_TRY(x, dcp_launch_path_blocks(c, a, x->d_ckpt_addr.p, B, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p),
+                DCP_EFUNCUSE);
+      else // DECIPHON_HIP_PATH_FUSED=0: a launch per block and phase (tests compare the two)
       {
         if (max_blocks > 1) HIP_TRY(x, dcp_launch_cost_ckpt(c, a, x->d_ckpt_addr.p, B), DCP_EFUNCUSE);
         for (int block = max_blocks - 1; block >= 0; --block)

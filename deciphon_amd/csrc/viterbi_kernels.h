@@ -54,6 +54,10 @@ hipError_t dcp_launch_cost_ckpt(int cls, DcpLaunch const &a, int64_t const *ckpt
 hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block);
 hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps,
                                 DcpTraceState *states, int B, int block);
+// the same for every window of a.problems (one class, not the strip class) in ONE launch: a workgroup takes its window
+// through the checkpoints, then block by block through rows + traceback (DcpProblem::trellis = the table's address)
+hipError_t dcp_launch_path_blocks(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, uint32_t *steps,
+                                  int64_t const *step_off, int32_t *nsteps, DcpTraceState *states);
 // strip class: the trellis replayed row by row from the DP tables at table_addr[out] (scratch: 3*K floats per row)
 hipError_t dcp_launch_replay(DcpLaunch const &a, int64_t const *table_addr, int64_t const *scratch_addr, int max_rows);
 hipError_t dcp_launch_compact_steps(uint32_t const *steps, int64_t const *step_off, int64_t const *compact_off,

@@ -411,6 +411,83 @@ __global__ __launch_bounds__(64) void dcp_traceback_kernel(
   }
 }
 
+// The fast path pass of ONE window from start to end in one workgroup (what dcp_cost_ckpt_kernel, then per block
+// dcp_cost_store_kernel + dcp_traceback_kernel do in 1 + 2 x blocks launches): the checkpoints, then block by block
+// from the last to the first the rows of the block into the window's table and the traceback through them by the
+// workgroup's first wavefront.  Windows of one launch no longer wait for each other between blocks -- a window of
+// two blocks is done after two -- and nothing returns to the host in between.  The table rows a traceback reads
+// were written by wavefronts of its own workgroup: the workgroup barrier orders them (one CU, one vector L1).
+template <int Q, int W>
+__global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_path_blocks_kernel(
+    float const *__restrict__ pool, DcpProfileDev const *__restrict__ profiles, DcpProblem const *__restrict__ problems,
+    DcpCodeRow const *__restrict__ code_rows, float const *__restrict__ xt_table, int64_t const *__restrict__ ckpt_addr,
+    int B, float *__restrict__ out, uint32_t *__restrict__ steps, int64_t const *__restrict__ step_off,
+    int32_t *__restrict__ nsteps, DcpTraceState *__restrict__ states, int nprob)
+{
+  if ((int)blockIdx.x >= nprob) return;
+  __shared__ int walk_over;
+  DcpProblem const pb = problems[blockIdx.x];
+  DcpProfileDev const pf = profiles[pb.profile];
+  DcpCodeRow const *codes = code_rows + pb.code_row;
+  float const *xt = xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE;
+  int const nb = dcp_num_blocks(pb.L, B);
+  float *ckpt = nb > 1 ? reinterpret_cast<float *>((uintptr_t)ckpt_addr[pb.out]) : nullptr;
+  if (nb > 1)
+  {
+    CostWave<Q, W> w;
+    w.ckpt_out = ckpt;
+    w.ckpt_every = B;
+    w.init(pool, pf, codes, xt);
+    w.run(pb.L, out + 2 * (size_t)pb.out);
+  }
+  int const slots = dcp_block_slots(pb.L, B);
+  float *tab_sp = reinterpret_cast<float *>((uintptr_t)pb.trellis);
+  for (int block = nb - 1; block >= 0; --block)
+  {
+    __syncthreads(); // the checkpoints are written; the walk through the block above has left the table
+    {
+      CostWave<Q, W, true> w;
+      w.tab_sp = tab_sp;
+      w.tab_cells = tab_sp + (size_t)slots * DCP_SP_STRIDE;
+      w.row_base = block * B;
+      if (block > 0) w.ckpt_in = ckpt + (size_t)(block - 1) * (size_t)dcp_ckpt_floats(pf.Kp, W);
+      w.init(pool, pf, codes, xt);
+      int const last = B > 0 ? (block + 1) * B + 5 : pb.L;
+      w.run(pb.L, out + 2 * (size_t)pb.out, last < pb.L ? last : pb.L);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < 64)
+    {
+      DcpTraceState *st = states + pb.out;
+      DcpTraceIn in;
+      in.K = pf.K;
+      in.Kp = pf.Kp;
+      in.L = pb.L;
+      in.sp = tab_sp;
+      in.cells = tab_sp + (size_t)slots * DCP_SP_STRIDE;
+      in.rows = pool + pf.rows_off;
+      in.trans = pool + pf.trans_off;
+      in.codes = codes;
+      in.xt = xt;
+      in.row_base = block * B;
+      in.lo = block > 0 ? block * B + 5 : -1;
+      int const r = dcp_traceback_wave(in, steps + step_off[pb.out], step_off[pb.out + 1] - step_off[pb.out], st);
+      if (threadIdx.x == 0)
+      {
+        walk_over = r != 0;
+        if (r != 0)
+        {
+          st->status = r > 0 ? 1 : r;
+          nsteps[pb.out] = r;
+        }
+      }
+    }
+    __syncthreads();
+    if (walk_over) break; // finished, or given up (a tie the values cannot resolve: the literal pass takes it)
+  }
+}
+
 // All single-wave classes in one launch: small scans (a few thousand windows spread
 // over several classes) would otherwise run their per-class kernels one after the
 // other, each too small to fill 1024 SIMDs.  Costs the register budget of the
@@ -846,6 +923,36 @@ hipError_t dcp_launch_cost_ckpt(int cls, DcpLaunch const &a, int64_t const *ckpt
   case 8: return launch_ckpt_qw<6, 4>(a, ckpt_addr, B);
   case 9: return launch_ckpt_qw<8, 4>(a, ckpt_addr, B);
   case 10: return launch_ckpt_qw<8, 8>(a, ckpt_addr, B);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+template <int Q, int W>
+static hipError_t launch_path_blocks_qw(DcpLaunch const &a, int64_t const *ckpt_addr, int B, uint32_t *steps,
+                                        int64_t const *step_off, int32_t *nsteps, DcpTraceState *states)
+{
+  hipLaunchKernelGGL((dcp_path_blocks_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool, a.profiles,
+                     a.problems, a.code_rows, a.xt_table, ckpt_addr, B, a.out, steps, step_off, nsteps, states, a.nprob);
+  return hipGetLastError();
+}
+
+hipError_t dcp_launch_path_blocks(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, uint32_t *steps,
+                                  int64_t const *step_off, int32_t *nsteps, DcpTraceState *states)
+{
+  if (a.nprob <= 0) return hipSuccess;
+  switch (cls)
+  {
+  case 0: return launch_path_blocks_qw<1, 1>(a, ckpt_addr, B, steps, step_off, nsteps, states);
+  case 1: return launch_path_blocks_qw<2, 1>(a, ckpt_addr, B, steps, step_off, nsteps, states);
+  case 2: return launch_path_blocks_qw<3, 1>(a, ckpt_addr, B, steps, step_off, nsteps, states);
+  case 3: return launch_path_blocks_qw<4, 1>(a, ckpt_addr, B, steps, step_off, nsteps, states);
+  case 4: return launch_path_blocks_qw<6, 1>(a, ckpt_addr, B, steps, step_off, nsteps, states);
+  case 5: return launch_path_blocks_qw<8, 1>(a, ckpt_addr, B, steps, step_off, nsteps, states);
+  case 6: return launch_path_blocks_qw<6, 2>(a, ckpt_addr, B, steps, step_off, nsteps, states);
+  case 7: return launch_path_blocks_qw<4, 4>(a, ckpt_addr, B, steps, step_off, nsteps, states);
+  case 8: return launch_path_blocks_qw<6, 4>(a, ckpt_addr, B, steps, step_off, nsteps, states);
+  case 9: return launch_path_blocks_qw<8, 4>(a, ckpt_addr, B, steps, step_off, nsteps, states);
+  case 10: return launch_path_blocks_qw<8, 8>(a, ckpt_addr, B, steps, step_off, nsteps, states);
   default: return hipErrorInvalidValue;
   }
 }
