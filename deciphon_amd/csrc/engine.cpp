@@ -37,21 +37,12 @@ template <class T> struct DevBuf
 {
   T *p = nullptr;
   size_t cap = 0; // elements
-  bool borrowed = false; // the memory belongs to another engine (dcp_hip_view_refresh)
   ~DevBuf() { release(); }
   void release()
   {
-    if (p && !borrowed) (void)hipFree(p);
+    if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
-    borrowed = false;
-  }
-  void borrow(DevBuf const &o)
-  {
-    release();
-    p = o.p;
-    cap = o.cap;
-    borrowed = o.p != nullptr;
   }
   hipError_t reserve(size_t n)
   {
@@ -271,6 +262,16 @@ struct Staged
   int pg_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
   double cells = 0;
   size_t arena_bytes = 0;
+  // stage() enqueues copies that read the vectors above; whoever owns a Staged may leave early on an error, so the
+  // vectors are not released before the stream has passed those copies (a no-op once the owner has synchronised)
+  hipStream_t pending = nullptr;
+  Staged() = default;
+  Staged(Staged const &) = delete;
+  Staged &operator=(Staged const &) = delete;
+  ~Staged()
+  {
+    if (pending) (void)hipStreamSynchronize(pending);
+  }
 };
 
 enum ArenaKind { ARENA_NONE, ARENA_TRELLIS, ARENA_TABLE };
@@ -292,6 +293,71 @@ size_t block_table_bytes(int L, int Kp, int B) { return (size_t)dcp_block_slots(
 size_t ckpt_bytes(int L, int Kp, int W, int B) { return (size_t)(dcp_num_blocks(L, B) - 1) * (size_t)dcp_ckpt_floats(Kp, W) * 4; }
 size_t fast_bytes(int L, int Kp, int W, int B) { return ((block_table_bytes(L, Kp, B) + 15) & ~(size_t)15) + ckpt_bytes(L, Kp, W, B); }
 
+// v reordered by key(v[i]) in [0, nkeys), equal keys keeping their order: count, prefix, scatter
+template <class Key> void bucket_stable(std::vector<DcpProblem> &v, int nkeys, Key key)
+{
+  std::vector<size_t> at((size_t)nkeys + 1, 0);
+  std::vector<unsigned char> k(v.size());
+  for (size_t i = 0; i < v.size(); ++i) ++at[(size_t)(k[i] = (unsigned char)key(v[i])) + 1];
+  bool one = false;
+  for (int j = 0; j < nkeys; ++j)
+  {
+    one = one || at[(size_t)j + 1] == v.size();
+    at[(size_t)j + 1] += at[(size_t)j];
+  }
+  if (one) return; // a single key: already in order
+  std::vector<DcpProblem> out(v.size());
+  for (size_t i = 0; i < v.size(); ++i) out[at[k[i]]++] = v[i];
+  v.swap(out);
+}
+
+// the n problems at p ordered by window length, longest first, equal lengths keeping their order
+void longest_first(DcpProblem *p, size_t n)
+{
+  if (n < 2) return;
+  int lens[32];
+  int nl = 0;
+  bool sorted = true;
+  for (size_t i = 0; i < n && nl <= 32; ++i)
+  {
+    sorted = sorted && (i == 0 || p[i].L <= p[i - 1].L);
+    int j = 0;
+    while (j < nl && lens[j] != p[i].L) ++j;
+    if (j == nl)
+    {
+      if (nl == 32)
+      {
+        nl = 33;
+        break;
+      }
+      lens[nl++] = p[i].L;
+    }
+  }
+  if (sorted && nl <= 32) return;
+  if (nl > 32)
+  {
+    std::stable_sort(p, p + n, [](DcpProblem const &a, DcpProblem const &b) { return a.L > b.L; });
+    return;
+  }
+  std::sort(lens, lens + nl, [](int a, int b) { return a > b; });
+  size_t at[33] = {0};
+  for (size_t i = 0; i < n; ++i)
+  {
+    int j = 0;
+    while (lens[j] != p[i].L) ++j;
+    ++at[j + 1];
+  }
+  for (int j = 0; j < nl; ++j) at[j + 1] += at[j];
+  std::vector<DcpProblem> out(n);
+  for (size_t i = 0; i < n; ++i)
+  {
+    int j = 0;
+    while (lens[j] != p[i].L) ++j;
+    out[at[j]++] = p[i];
+  }
+  std::copy(out.begin(), out.end(), p);
+}
+
 // validates windows and builds the device problem list
 int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Staged &st)
 {
@@ -301,8 +367,10 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
   int max_s = 1;
   st.problems.resize((size_t)n);
   size_t arena = 0;
+  bool by_profile = true; // the windows come in ascending profile order (dcp_scan_run's do): no sort needed below
   for (int i = 0; i < n; ++i)
   {
+    by_profile = by_profile && (i == 0 || w[i].profile >= w[i - 1].profile);
     if (w[i].profile < 0 || w[i].profile >= (int)x->profiles.size()) return fail(x, DCP_EFUNCUSE, "bad profile index");
     if (w[i].seq < 0 || w[i].seq >= nseq) return fail(x, DCP_EFUNCUSE, "bad sequence index");
     int64_t const len = x->seq_off[(size_t)w[i].seq + 1] - x->seq_off[(size_t)w[i].seq];
@@ -344,12 +412,27 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
     std::vector<DcpProblem> packed, rest;
     for (DcpProblem const &p : st.problems)
       (x->profiles[(size_t)p.profile].pack >= 0 ? packed : rest).push_back(p);
-    std::stable_sort(packed.begin(), packed.end(), [&](DcpProblem const &a, DcpProblem const &b) {
-      int sa = x->profiles[(size_t)a.profile].pack, sb = x->profiles[(size_t)b.profile].pack;
-      if (sa != sb) return sa < sb;
-      if (a.profile != b.profile) return a.profile < b.profile;
-      return a.L > b.L;
-    });
+    if (by_profile)
+    {
+      // order (shape, profile, longest first) without a comparison sort over everything: a stable scatter by shape
+      // keeps the profiles ascending, then each profile's run is ordered by length -- a counting pass when the run
+      // holds few distinct lengths (the windows of a chain: whole windows and one tail)
+      bucket_stable(packed, DCP_NUM_PACK_SHAPES, [&](DcpProblem const &a) { return x->profiles[(size_t)a.profile].pack; });
+      for (size_t b = 0; b < packed.size();)
+      {
+        size_t e = b + 1;
+        while (e < packed.size() && packed[e].profile == packed[b].profile) ++e;
+        longest_first(packed.data() + b, e - b);
+        b = e;
+      }
+    }
+    else
+      std::stable_sort(packed.begin(), packed.end(), [&](DcpProblem const &a, DcpProblem const &b) {
+        int sa = x->profiles[(size_t)a.profile].pack, sb = x->profiles[(size_t)b.profile].pack;
+        if (sa != sb) return sa < sb;
+        if (a.profile != b.profile) return a.profile < b.profile;
+        return a.L > b.L;
+      });
     int shape = 0;
     for (size_t i = 0; i < packed.size();)
     {
@@ -394,12 +477,20 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
     st.pg_begin[DCP_NUM_PACK_SHAPES] = (int)st.pack_groups.size();
   }
   int const nu = (int)st.problems.size(); // windows that keep a wavefront (or a workgroup) to themselves
-  std::stable_sort(st.problems.begin(), st.problems.end(), [&](DcpProblem const &a, DcpProblem const &b) {
-    HostProfile const &pa = x->profiles[(size_t)a.profile], &pb = x->profiles[(size_t)b.profile];
-    if (pa.cls != pb.cls) return pa.cls < pb.cls;
-    if (pa.narrow != pb.narrow) return pa.narrow; // one position per lane less: their own launch of the cost pass
-    return a.profile < b.profile;
-  });
+  // by (class, the narrow profiles of a class first -- one position per lane less: their own launch of the cost pass --,
+  // profile)
+  if (by_profile)
+    bucket_stable(st.problems, 2 * DCP_NUM_CLASSES, [&](DcpProblem const &a) {
+      HostProfile const &hp = x->profiles[(size_t)a.profile];
+      return 2 * hp.cls + (hp.narrow ? 0 : 1);
+    });
+  else
+    std::stable_sort(st.problems.begin(), st.problems.end(), [&](DcpProblem const &a, DcpProblem const &b) {
+      HostProfile const &pa = x->profiles[(size_t)a.profile], &pb = x->profiles[(size_t)b.profile];
+      if (pa.cls != pb.cls) return pa.cls < pb.cls;
+      if (pa.narrow != pb.narrow) return pa.narrow;
+      return a.profile < b.profile;
+    });
   int i = 0;
   for (int c = 0; c < DCP_NUM_CLASSES; ++c)
   {
@@ -417,26 +508,23 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
   int rc = ensure_xt(x, max_s + 1);
   if (rc) return rc;
   x->staged_n = -1; // the device problem list is about to be replaced
+  // every allocation first: after the first copy is enqueued nothing below can fail but a copy itself
   HIP_TRY(x, x->d_problems.reserve((size_t)std::max(nu, 1)), DCP_ENOMEM);
+  if (!st.packs.empty()) HIP_TRY(x, x->d_packs.reserve(st.packs.size()), DCP_ENOMEM);
+  if (!st.pack_groups.empty()) HIP_TRY(x, x->d_pack_groups.reserve(st.pack_groups.size()), DCP_ENOMEM);
+  st.pending = x->stream;
   if (nu)
     HIP_TRY(x, hipMemcpyAsync(x->d_problems.p, st.problems.data(), (size_t)nu * sizeof(DcpProblem),
                               hipMemcpyHostToDevice, x->stream),
             DCP_EFUNCUSE);
   if (!st.packs.empty())
-  {
-    HIP_TRY(x, x->d_packs.reserve(st.packs.size()), DCP_ENOMEM);
     HIP_TRY(x, hipMemcpyAsync(x->d_packs.p, st.packs.data(), st.packs.size() * sizeof(DcpPack), hipMemcpyHostToDevice,
                               x->stream),
             DCP_EFUNCUSE);
-    // st.packs is read by the copy until the stream gets there; the callers keep `st` alive across their sync
-    if (!st.pack_groups.empty())
-    {
-      HIP_TRY(x, x->d_pack_groups.reserve(st.pack_groups.size()), DCP_ENOMEM);
-      HIP_TRY(x, hipMemcpyAsync(x->d_pack_groups.p, st.pack_groups.data(), st.pack_groups.size() * sizeof(int2),
-                                hipMemcpyHostToDevice, x->stream),
-              DCP_EFUNCUSE);
-    }
-  }
+  if (!st.pack_groups.empty())
+    HIP_TRY(x, hipMemcpyAsync(x->d_pack_groups.p, st.pack_groups.data(), st.pack_groups.size() * sizeof(int2),
+                              hipMemcpyHostToDevice, x->stream),
+            DCP_EFUNCUSE);
   return 0;
 }
 
@@ -639,39 +727,6 @@ struct dcp_hip *dcp_hip_new(int device)
   x->seq_off.assign(1, 0);
   x->row_off.assign(1, 0);
   return x;
-}
-
-// A second engine over the SAME database and reads (dcp_scan_run: the path pass of one round of windows runs on
-// it, from a host thread of its own, while the first engine runs the cost pass of the next round): the view
-// borrows the parent's profile pool, descriptors, code rows and mode, and has its own streams, problem lists,
-// DP tables and results.  Call again after anything of that changed on the parent; the parent must outlive the view.
-int dcp_hip_view_refresh(struct dcp_hip *view, struct dcp_hip const *parent)
-{
-  if (!view || !parent || view == parent || view->device != parent->device) return DCP_EFUNCUSE;
-  HIP_TRY(view, hipSetDevice(view->device), DCP_EFUNCUSE);
-  HIP_TRY(view, hipStreamSynchronize(view->stream), DCP_EFUNCUSE);
-  view->profiles = parent->profiles;
-  view->committed = parent->committed;
-  view->pool_used = parent->pool_used;
-  view->d_pool.borrow(parent->d_pool);
-  view->d_profiles.borrow(parent->d_profiles);
-  view->seq_off = parent->seq_off;
-  view->row_off = parent->row_off;
-  view->d_nt.borrow(parent->d_nt);
-  view->d_seq_off.borrow(parent->d_seq_off);
-  view->d_row_off.borrow(parent->d_row_off);
-  view->d_rows.borrow(parent->d_rows);
-  if (view->mode_set && (view->multi_hits != parent->multi_hits || view->hmmer3_compat != parent->hmmer3_compat)) view->xt_rows = 0;
-  view->mode_set = parent->mode_set;
-  view->multi_hits = parent->multi_hits;
-  view->hmmer3_compat = parent->hmmer3_compat;
-  if (view->xt_override != parent->xt_override)
-  {
-    view->xt_override = parent->xt_override;
-    view->xt_rows = 0;
-  }
-  view->staged_n = -1;
-  return 0;
 }
 
 void dcp_hip_del(struct dcp_hip *x)

@@ -9,11 +9,10 @@
 // The reference walks profile-major: for each profile, for each read, for each
 // window -- one DP at a time per thread.  Windows of ONE (profile, read) pair form
 // a chain (the next window starts after the previous window's hit,
-// c-core/window.c:21-31), but different pairs are independent, so the scan runs
-// in ROUNDS: round r scores window r of every pair that still has one, all in one
-// launch; the windows that pass the lrt filter go through the path pass together;
-// their hits set last_hit_pos and the pairs advance.  Rows are emitted in the
-// reference's order (profile, then read, then window) whatever the round order.
+// c-core/window.c:21-31), but different pairs are independent and hits are rare:
+// dcp_scan_run scores the no-hit chain of every pair in one launch and then lets
+// only the pairs that did hit walk their real chains (see there).  Rows are emitted
+// in the reference's order (profile, then read, then window) whatever the order of work.
 #include "../../include/deciphon.h"
 #include "../../include/deciphon_hip.h"
 #include "dcp_db.h"
@@ -29,7 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <deque>
-#include <future>
+#include <map>
 #include <memory>
 #include <string>
 #include <sys/stat.h>
@@ -52,7 +51,6 @@ struct dcp_batch
 struct dcp_scan
 {
   dcp_hip *eng = nullptr;
-  dcp_hip *eng_path = nullptr; // a view of eng (dcp_hip_view_refresh): the path passes, overlapped with the cost passes
   int device = 0;
   bool multi_hits = true, hmmer3_compat = false;
   void (*callback)(void *) = nullptr;
@@ -117,14 +115,6 @@ struct Phase
     t = n;
     return d;
   }
-};
-
-struct Pair
-{
-  int profile, seq;
-  DcpWindow win;
-  bool active = true;
-  Pair(int p, int s, int seq_size, int core_size) : profile(p), seq(s), win(seq_size, core_size) {}
 };
 
 struct Row
@@ -252,20 +242,16 @@ int setup_common(dcp_scan *x, char const *dbfile, int device, int index, int npa
   x->db.reset(new DcpDbReader);
   if ((rc = x->db->open(dbfile))) return raise(rc, __func__, dbfile);
   x->decoders.clear();
-  if (x->eng_path) dcp_hip_del(x->eng_path); // the view first: it borrows the other's tables
-  x->eng_path = nullptr;
   if (x->eng) dcp_hip_del(x->eng);
   x->eng = dcp_hip_new(device);
   if (!x->eng) return raise(DCP_EFUNCUSE, __func__, "no usable HIP device (there is no CPU fallback)");
-  x->eng_path = dcp_hip_new(device);
-  if (!x->eng_path) return raise(DCP_EFUNCUSE, __func__, "no second engine for the path passes");
   x->device = device;
   {
     // HBM for the path pass's DP tables, first: VRAM is cleared on allocation, in the background,
     // and the clearing then overlaps the database load and the first cost pass.  Best effort:
     // dcp_hip_path allocates what it needs anyway.
     char const *mb = getenv("DECIPHON_HIP_PATH_BUDGET_MB");
-    (void)dcp_hip_path_reserve(x->eng_path, mb ? (int64_t)std::max(atol(mb), 1L) << 20 : (int64_t)4 << 30);
+    (void)dcp_hip_path_reserve(x->eng, mb ? (int64_t)std::max(atol(mb), 1L) << 20 : (int64_t)4 << 30);
   }
   if (x->num_proteins > 0)
   {
@@ -293,7 +279,6 @@ void dcp_scan_del(struct dcp_scan const *cx)
 {
   dcp_scan *x = const_cast<dcp_scan *>(cx);
   if (!x) return;
-  if (x->eng_path) dcp_hip_del(x->eng_path);
   if (x->eng) dcp_hip_del(x->eng);
   delete x;
 }
@@ -352,14 +337,13 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   for (int i = 0; i < nseq; ++i)
     memcpy(nt.data() + off[(size_t)i], batch->seqs[(size_t)i].nt.data(), batch->seqs[(size_t)i].nt.size());
   if ((rc = dcp_hip_set_sequences(x->eng, nseq, nt.data(), off.data()))) return raise(rc, __func__, dcp_hip_strerror(x->eng));
-  if ((rc = dcp_hip_view_refresh(x->eng_path, x->eng))) return raise(rc, __func__, dcp_hip_strerror(x->eng_path));
 
   // product_open (c-core/product.c:14-32)
   std::string const dir = product_dir;
   if ((rc = mkdir_p(dir))) return raise(rc, __func__, product_dir);
 
   std::vector<Row> rows;
-  // rows are formatted off the main thread, one task per round; joined before the sort below
+  // rows are formatted off the main thread, one task per path pass; joined before the sort below
   struct Job
   {
     int profile, seq, widx, wstart, wstop;
@@ -387,169 +371,253 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   int rounds = 0;
   size_t nwindows = 0, nhits = 0;
   int const nprof = dcp_hip_num_profiles(x->eng);
-  // profiles are walked in chunks so that the pair table stays small
+  // Windows of ONE (profile, read) pair form a chain -- where window w + 1 starts depends on the hit of window w
+  // (c-core/window.c:21-31, c-core/thread.c:162) -- but hits are rare, and while a pair has had none its chain is the
+  // same for every pair with that read length and core size.  So a chunk of profiles is scored SPECULATIVELY: every
+  // window of every pair's no-hit chain in one launch (cost pass + LRT filter on the device, c-core/thread.c:114-121).
+  // Pairs without a hit are done.  A pair with hits then walks its real chain: the path pass of its first hit
+  // (c-core/thread.c:123-166) sets last_hit_pos; while the windows that follow are still the speculated ones their
+  // scores stand, otherwise they are scored again -- in rounds over the few pairs concerned, the path passes of a
+  // round in one call.  Rows are emitted in the reference's order (profile, read, window) whatever the order of work.
+  // DECIPHON_HIP_SPECULATE=0: nothing is assumed, every pair goes round by round (the tests compare the two).
+  char const *spec_env = getenv("DECIPHON_HIP_SPECULATE");
+  bool const speculate = !(spec_env && spec_env[0] == '0');
+  // profiles are walked in chunks so that the window table stays small
   size_t const max_pairs = 1u << 21;
   int chunk = nseq > 0 ? (int)std::max<size_t>(1, max_pairs / (size_t)nseq) : nprof;
+  typedef std::vector<std::pair<int, int>> Chain; // [start, stop) of the windows of a pair that never hits
+  std::map<std::pair<int, int>, Chain> chains;    // by (read length, core size)
+  auto chain_of = [&](int seq_size, int core_size) -> Chain const * {
+    auto it = chains.find({seq_size, core_size});
+    if (it == chains.end())
+    {
+      Chain c;
+      DcpWindow w(seq_size, core_size);
+      while (w.next()) c.emplace_back(w.start, w.stop);
+      it = chains.emplace(std::make_pair(seq_size, core_size), std::move(c)).first;
+    }
+    return &it->second;
+  };
   for (int p0 = 0; p0 < nprof && !x->interrupted; p0 += chunk)
   {
     int const p1 = std::min(nprof, p0 + chunk);
-    std::vector<Pair> pairs;
-    for (int p = p0; p < p1; ++p)
-      for (int s = 0; s < nseq; ++s)
-        if (!batch->seqs[(size_t)s].nt.empty())
-          pairs.emplace_back(p, s, (int)batch->seqs[(size_t)s].nt.size(), dcp_hip_profile_core_size(x->eng, p));
-    // Rounds.  A round is the next window of every pair that is not waiting for a path pass: cost pass + LRT filter
-    // on x->eng (c-core/thread.c:114-121), then the path pass of the round's hits on x->eng_path, from a thread of
-    // its own, WHILE the next round's cost pass runs -- a pair with a hit sits that round out (its next window
-    // starts from the hit, c-core/thread.c:162) and rejoins the one after.  Pairs are independent and the rows are
-    // sorted at the end, so products.tsv does not change.  DECIPHON_HIP_OVERLAP=0: one after the other.
-    struct Pending
+    struct PairState
     {
-      std::vector<dcp_hip_window> hits;
-      std::vector<size_t> pair_of;
-      std::vector<float> lrts;
-      std::future<int> done;
+      int profile, seq;
+      DcpWindow win;
+      Chain const *spec; // the speculated chain, scores at spec_lrt[base ..]; nullptr: nothing speculated
+      size_t base;
     };
-    std::unique_ptr<Pending> pending;
-    char const *overlap_env = getenv("DECIPHON_HIP_OVERLAP");
-    bool const overlap = !(overlap_env && overlap_env[0] == '0');
-    std::vector<char> waiting(pairs.size(), 0);
-    // the finished path pass: hit spans first (they move the window chains); the rows are then formatted by up to
-    // 16 host threads (a row is a few thousand short appends) while the next rounds run on the GPU
-    auto collect = [&](Pending &pd) -> int {
-      int prc = pd.done.get();
-      if (prc) return raise(prc, __func__, dcp_hip_strerror(x->eng_path));
-      ph.path += ph.lap();
-      auto jobs = std::make_shared<std::vector<Job>>();
-      for (size_t h = 0; h < pd.hits.size(); ++h)
-      {
-        waiting[pd.pair_of[h]] = 0;
-        int const n = dcp_hip_path_nsteps(x->eng_path, (int)h);
-        Job j;
-        j.ids.resize((size_t)n);
-        j.sizes.resize((size_t)n);
-        if ((prc = dcp_hip_path_steps(x->eng_path, (int)h, j.ids.data(), j.sizes.data()))) return raise(prc, __func__);
-        if (!dcp_find_hit(j.ids, j.sizes, j.hit)) continue;
-        Pair &pr = pairs[pd.pair_of[h]];
-        pr.win.last_hit_pos = j.hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
-        j.profile = pr.profile;
-        j.seq = pr.seq;
-        j.widx = pr.win.idx;
-        j.wstart = pr.win.start;
-        j.wstop = pr.win.stop;
-        j.lrt = pd.lrts[h];
-        if (!x->decoders[(size_t)pr.profile]) // decoder_setup, c-core/decoder.c:21-36
-        {
-          auto dec = std::make_shared<DcpDecoder>();
-          if ((prc = x->db->read_decoder(x->index_offset + pr.profile, *dec))) return raise(prc, __func__);
-          x->decoders[(size_t)pr.profile] = dec;
-        }
-        j.dec = x->decoders[(size_t)pr.profile];
-        jobs->push_back(std::move(j));
-      }
-      if (!jobs->empty())
-      {
-        formatted.emplace_back(jobs->size());
-        std::vector<Row> *out = &formatted.back();
-        dcp_scan const *scan = x;
-        std::atomic<int> *drc = &decode_rc;
-        formatters.add(std::thread([jobs, out, scan, batch, drc]() {
-          std::atomic<size_t> next_job{0};
-          auto work = [&]() {
-            for (size_t k = next_job.fetch_add(1); k < jobs->size(); k = next_job.fetch_add(1))
-            {
-              Job const &j = (*jobs)[k];
-              dcp_batch::Seq const &seq = batch->seqs[(size_t)j.seq];
-              (*out)[k] = Row{j.profile, j.seq, j.widx,
-                              format_row(seq, j.widx, j.wstart, j.wstop, j.hit,
-                                         dcp_hip_profile_accession(scan->eng, j.profile), scan->abc_name.c_str(),
-                                         j.lrt, j.ids, j.sizes, *j.dec, drc)};
-            }
-          };
-          unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
-                                                        (unsigned)std::max<size_t>(jobs->size() / 8, 1)});
-          std::vector<std::thread> pool;
-          for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
-          work();
-          for (std::thread &t : pool) t.join();
-        }));
-      }
-      ph.rows += ph.lap();
-      return 0;
+    struct Work
+    {
+      size_t pair;
+      dcp_hip_window w;
+      float lrt;
     };
-    for (;;)
+    std::vector<PairState> st;
+    std::vector<float> spec_lrt; // per speculated window: its lrt when it passed the filter, -1 otherwise
+    std::vector<Work> need_cost, need_path;
+    size_t callbacks_due = 0;
+
+    if (speculate)
     {
       std::vector<dcp_hip_window> wins;
-      std::vector<size_t> owner;
-      for (size_t i = 0; i < pairs.size(); ++i)
+      std::vector<size_t> base; // first window of pair (p - p0) * nseq + s
+      base.reserve((size_t)(p1 - p0) * (size_t)nseq + 1);
+      for (int pass = 0; pass < 2; ++pass) // count, then fill
       {
-        Pair &pr = pairs[i];
-        if (!pr.active || waiting[i]) continue;
-        if (!pr.win.next())
+        size_t n = 0;
+        for (int p = p0; p < p1; ++p)
         {
-          pr.active = false;
-          continue;
+          int const K = dcp_hip_profile_core_size(x->eng, p);
+          int last_len = -1;
+          Chain const *ch = nullptr; // reads of one length follow each other more often than not
+          for (int s = 0; s < nseq; ++s)
+          {
+            int const len = (int)batch->seqs[(size_t)s].nt.size();
+            if (len != last_len) ch = len > 0 ? chain_of(last_len = len, K) : nullptr;
+            if (len == 0) last_len = 0;
+            if (pass == 1)
+            {
+              base.push_back(n);
+              if (ch)
+              {
+                dcp_hip_window *w = wins.data() + n;
+                for (std::pair<int, int> const &r : *ch) *w++ = dcp_hip_window{p, s, r.first, r.second};
+              }
+            }
+            n += ch ? ch->size() : 0;
+          }
         }
-        wins.push_back(dcp_hip_window{pr.profile, pr.seq, pr.win.start, pr.win.stop});
-        owner.push_back(i);
+        if (pass == 0) wins.resize(n);
       }
-      if (wins.empty() && !pending) break;
+      base.push_back(wins.size());
       ph.windows += ph.lap();
-      // c-core/thread.c:114-121: null and alternative scores, lrt and its filter -- all on the device; what comes
-      // back are the windows that go on to the path pass
       std::vector<int32_t> hit_index(wins.size());
       std::vector<float> lrts(wins.size());
       int nh = 0;
       if (!wins.empty())
       {
         ++rounds;
-        nwindows += wins.size();
         if ((rc = dcp_hip_cost_hits(x->eng, (int)wins.size(), wins.data(), &nh, hit_index.data(), lrts.data())))
-        {
-          if (pending) (void)pending->done.get();
           return raise(rc, __func__, dcp_hip_strerror(x->eng));
-        }
       }
       ph.cost += ph.lap();
-      if (pending) // the path pass that ran meanwhile
+      spec_lrt.assign(wins.size(), -1.0f);
+      size_t speculated_of_hit_pairs = 0;
+      for (int h = 0; h < nh; ++h) // hit_index ascends: the hits of a pair are neighbours
       {
-        rc = collect(*pending);
-        pending.reset();
-        if (rc) return rc;
+        size_t const wi = (size_t)hit_index[(size_t)h];
+        spec_lrt[wi] = lrts[(size_t)h];
+        size_t const pi = (size_t)(std::upper_bound(base.begin(), base.end(), wi) - base.begin()) - 1;
+        if (!st.empty() && st.back().base == base[pi]) continue;
+        int const p = p0 + (int)(pi / (size_t)nseq), sq = (int)(pi % (size_t)nseq);
+        int const len = (int)batch->seqs[(size_t)sq].nt.size(), K = dcp_hip_profile_core_size(x->eng, p);
+        st.push_back(PairState{p, sq, DcpWindow(len, K), chain_of(len, K), base[pi]});
+        speculated_of_hit_pairs += base[pi + 1] - base[pi];
       }
-      if (nh > 0)
+      // the windows of the pairs without a hit are final: one callback each (c-core/thread.c:74); the pairs with a
+      // hit report theirs as their real chains advance
+      nwindows += wins.size() - speculated_of_hit_pairs;
+      callbacks_due = wins.size() - speculated_of_hit_pairs;
+    }
+    else
+    {
+      for (int p = p0; p < p1; ++p)
+        for (int s = 0; s < nseq; ++s)
+          if (!batch->seqs[(size_t)s].nt.empty())
+            st.push_back(PairState{p, s, DcpWindow((int)batch->seqs[(size_t)s].nt.size(), dcp_hip_profile_core_size(x->eng, p)),
+                                   nullptr, 0});
+    }
+    if (x->callback)
+      for (size_t i = 0; i < callbacks_due && !x->interrupted; ++i) x->callback(x->userdata);
+
+    // moves a pair to its next window that needs work: a path pass (a speculated window that passed the filter) or a
+    // cost pass (a window nobody has scored); nothing when its chain has ended
+    auto advance = [&](size_t i) {
+      PairState &ps = st[i];
+      while (ps.win.next())
       {
-        pending.reset(new Pending);
-        pending->hits.resize((size_t)nh);
-        pending->pair_of.resize((size_t)nh);
-        pending->lrts.assign(lrts.begin(), lrts.begin() + nh);
+        ++nwindows;
+        if (x->callback) x->callback(x->userdata);
+        dcp_hip_window const w{ps.profile, ps.seq, ps.win.start, ps.win.stop};
+        bool const as_speculated = ps.spec && (size_t)ps.win.idx < ps.spec->size() &&
+                                   (*ps.spec)[(size_t)ps.win.idx] == std::make_pair(ps.win.start, ps.win.stop);
+        if (!as_speculated)
+        {
+          need_cost.push_back(Work{i, w, 0.0f});
+          return;
+        }
+        float const lrt = spec_lrt[ps.base + (size_t)ps.win.idx];
+        if (lrt >= 0.0f)
+        {
+          need_path.push_back(Work{i, w, lrt});
+          return;
+        }
+      }
+    };
+    for (size_t i = 0; i < st.size(); ++i) advance(i);
+    ph.windows += ph.lap();
+
+    while ((!need_cost.empty() || !need_path.empty()) && !x->interrupted)
+    {
+      if (!need_cost.empty()) // c-core/thread.c:114-121 for the windows nobody has scored yet
+      {
+        std::vector<Work> batch_c;
+        batch_c.swap(need_cost);
+        std::vector<dcp_hip_window> wins(batch_c.size());
+        for (size_t k = 0; k < batch_c.size(); ++k) wins[k] = batch_c[k].w;
+        std::vector<int32_t> hit_index(wins.size());
+        std::vector<float> lrts(wins.size());
+        int nh = 0;
+        ++rounds;
+        ph.windows += ph.lap();
+        if ((rc = dcp_hip_cost_hits(x->eng, (int)wins.size(), wins.data(), &nh, hit_index.data(), lrts.data())))
+          return raise(rc, __func__, dcp_hip_strerror(x->eng));
+        ph.cost += ph.lap();
+        std::vector<char> is_hit(wins.size(), 0);
         for (int h = 0; h < nh; ++h)
         {
-          size_t const wi = (size_t)hit_index[(size_t)h];
-          pending->hits[(size_t)h] = wins[wi];
-          pending->pair_of[(size_t)h] = owner[wi];
-          waiting[owner[wi]] = 1;
+          size_t const k = (size_t)hit_index[(size_t)h];
+          is_hit[k] = 1;
+          need_path.push_back(Work{batch_c[k].pair, batch_c[k].w, lrts[(size_t)h]});
         }
-        nhits += (size_t)nh;
-        dcp_hip *const pe = x->eng_path;
-        Pending *const pd = pending.get();
-        pending->done = std::async(overlap ? std::launch::async : std::launch::deferred,
-                                   [pe, pd]() { return dcp_hip_path(pe, (int)pd->hits.size(), pd->hits.data()); });
-        if (!overlap)
-        {
-          rc = collect(*pending);
-          pending.reset();
-          if (rc) return rc;
-        }
+        for (size_t k = 0; k < batch_c.size(); ++k)
+          if (!is_hit[k]) advance(batch_c[k].pair);
+        ph.windows += ph.lap();
       }
-      if (x->callback)
-        for (size_t i = 0; i < wins.size(); ++i) x->callback(x->userdata); // once per window, c-core/thread.c:74
-      if (x->interrupted)
+      if (!need_path.empty()) // c-core/thread.c:123-166: viterbi_path, trellis_unzip, the hit span, last_hit_pos
       {
-        if (pending) (void)pending->done.get();
-        break;
+        std::vector<Work> batch_p;
+        batch_p.swap(need_path);
+        std::vector<dcp_hip_window> hits(batch_p.size());
+        for (size_t k = 0; k < batch_p.size(); ++k) hits[k] = batch_p[k].w;
+        nhits += hits.size();
+        if ((rc = dcp_hip_path(x->eng, (int)hits.size(), hits.data()))) return raise(rc, __func__, dcp_hip_strerror(x->eng));
+        ph.path += ph.lap();
+        // hit spans first (they move the window chains); the rows are then formatted by up to 16 host threads (a row
+        // is a few thousand short appends) while the GPU goes on
+        auto jobs = std::make_shared<std::vector<Job>>();
+        for (size_t h = 0; h < batch_p.size(); ++h)
+        {
+          int const n = dcp_hip_path_nsteps(x->eng, (int)h);
+          Job j;
+          j.ids.resize((size_t)n);
+          j.sizes.resize((size_t)n);
+          if ((rc = dcp_hip_path_steps(x->eng, (int)h, j.ids.data(), j.sizes.data()))) return raise(rc, __func__);
+          if (!dcp_find_hit(j.ids, j.sizes, j.hit)) continue;
+          PairState &ps = st[batch_p[h].pair];
+          ps.win.last_hit_pos = j.hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
+          j.profile = ps.profile;
+          j.seq = ps.seq;
+          j.widx = ps.win.idx;
+          j.wstart = ps.win.start;
+          j.wstop = ps.win.stop;
+          j.lrt = batch_p[h].lrt;
+          if (!x->decoders[(size_t)ps.profile]) // decoder_setup, c-core/decoder.c:21-36
+          {
+            auto dec = std::make_shared<DcpDecoder>();
+            if ((rc = x->db->read_decoder(x->index_offset + ps.profile, *dec))) return raise(rc, __func__);
+            x->decoders[(size_t)ps.profile] = dec;
+          }
+          j.dec = x->decoders[(size_t)ps.profile];
+          jobs->push_back(std::move(j));
+        }
+        if (!jobs->empty())
+        {
+          formatted.emplace_back(jobs->size());
+          std::vector<Row> *out = &formatted.back();
+          dcp_scan const *scan = x;
+          std::atomic<int> *drc = &decode_rc;
+          formatters.add(std::thread([jobs, out, scan, batch, drc]() {
+            std::atomic<size_t> next_job{0};
+            auto work = [&]() {
+              for (size_t k = next_job.fetch_add(1); k < jobs->size(); k = next_job.fetch_add(1))
+              {
+                Job const &j = (*jobs)[k];
+                dcp_batch::Seq const &seq = batch->seqs[(size_t)j.seq];
+                (*out)[k] = Row{j.profile, j.seq, j.widx,
+                                format_row(seq, j.widx, j.wstart, j.wstop, j.hit,
+                                           dcp_hip_profile_accession(scan->eng, j.profile), scan->abc_name.c_str(),
+                                           j.lrt, j.ids, j.sizes, *j.dec, drc)};
+              }
+            };
+            unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
+                                                          (unsigned)std::max<size_t>(jobs->size() / 8, 1)});
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+            work();
+            for (std::thread &t : pool) t.join();
+          }));
+        }
+        ph.rows += ph.lap();
+        for (Work const &wk : batch_p) advance(wk.pair);
+        ph.windows += ph.lap();
       }
     }
+    // the decoders of this chunk's profiles go with the chunk (a memo of (K + 3) * 1364 bytes each; the formatter
+    // jobs hold their own references): a Pfam-sized database with hits on most profiles would pin gigabytes
+    for (int p = p0; p < p1; ++p) x->decoders[(size_t)p].reset();
     x->done_proteins += p1 - p0;
   }
 

@@ -50,8 +50,6 @@ def load_library() -> C.CDLL:
     L.dcp_hip_del.restype = None
     L.dcp_hip_strerror.argtypes = [vp]
     L.dcp_hip_strerror.restype = C.c_char_p
-    L.dcp_hip_view_refresh.argtypes = [vp, vp]
-    L.dcp_hip_view_refresh.restype = C.c_int
     L.dcp_hip_add_profile.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(i32)]
     L.dcp_hip_add_protein.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.dcp_hip_load_dcp.argtypes = [vp, C.c_char_p, i32, i32]
@@ -158,24 +156,6 @@ class Engine:
     def _check(self, rc: int):
         if rc:
             raise HipError(rc, self.lib.dcp_hip_strerror(self.h).decode())
-
-    def view(self) -> "Engine":
-        """A second engine over this one's profiles, reads and mode without copying them (dcp_hip_view_refresh):
-        its own streams, window lists and results, so that another host thread can run passes on it meanwhile.
-        Call refresh_view() on it after this engine's profiles / reads / mode changed; close it first."""
-        v = Engine.__new__(Engine)
-        v.lib = self.lib
-        v.h = self.lib.dcp_hip_new(self.device)
-        if not v.h:
-            raise HipError(8, "no second engine")
-        v.device = self.device
-        v._parent = self
-        v.refresh_view()
-        return v
-
-    def refresh_view(self):
-        self._seq_lens = list(self._parent._seq_lens)
-        self._check(self.lib.dcp_hip_view_refresh(self.h, self._parent.h))
 
     # ---- profiles -------------------------------------------------------------
     def add_profile(self, K: int, trans, match, null, bg) -> int:

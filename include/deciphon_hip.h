@@ -39,13 +39,6 @@ struct dcp_hip *dcp_hip_new(int device);
 void dcp_hip_del(struct dcp_hip *);
 char const *dcp_hip_strerror(struct dcp_hip const *); /* detail of the last failure */
 
-/* Makes `view` (a dcp_hip_new of the same device) a second engine over the parent's database, reads and mode
- * WITHOUT copying them: it borrows the device tables and keeps its own streams, window lists, DP tables and
- * results, so that a host thread can run path passes on it while another runs cost passes on the parent
- * (dcp_scan_run overlaps the two: the work of c-core/thread.c:114-126 for different windows).  Call it again
- * after profiles, sequences or the mode of the parent changed; the parent must outlive the view. */
-int dcp_hip_view_refresh(struct dcp_hip *view, struct dcp_hip const *parent);
-
 /* ---- profiles (replaces work_setup -> protein_setup_viterbi, c-core/work.c:24-45) ----
  * dcp_hip_add_profile takes DP costs exactly as viterbi_set_core_trans /
  * _set_match / _set_null / _set_background receive them (c-core/viterbi.c:407-444):

@@ -169,49 +169,6 @@ def test_one_position_per_lane_less_than_the_class_layout(engine, orc, monkeypat
         assert bits(alt[i]) == bits(orc.cost(profs[pi], xt, reads[si])), wins[i]
 
 
-def test_view_engine_borrows_the_database_and_runs_beside_its_parent(engine, orc):
-    """dcp_hip_view_refresh: a second engine over the parent's profiles, reads and mode -- path passes on it from
-    another thread while the parent runs cost passes (what dcp_scan_run does) give the parent's own bits."""
-    import threading
-
-    rng = np.random.default_rng(77)
-    profs = [synth_profile(rng, K, None, 0.05) for K in (3, 40, 173, 300, 700)]
-    engine.clear_profiles()
-    for p in profs:
-        engine.add_profile(p.K, p.trans, p.match, p.null, p.bg)
-    engine.commit()
-    reads = [random_seq(rng, n) for n in (30, 200, 333, 90)]
-    engine.set_sequences(reads)
-    engine.set_mode(True, False)
-    wins = [(pi, si, 0, len(r)) for pi in range(len(profs)) for si, r in enumerate(reads)]
-    want = engine.path(wins, trellis=False)
-    nul0, alt0 = engine.cost(wins)
-    view = engine.view()
-    try:
-        got = {}
-        t = threading.Thread(target=lambda: got.setdefault("paths", view.path(wins, trellis=False)))
-        t.start()
-        for _ in range(5):  # the parent keeps its GPU busy meanwhile
-            nul, alt = engine.cost(wins)
-            assert np.array_equal(nul.view(np.uint32), nul0.view(np.uint32))
-            assert np.array_equal(alt.view(np.uint32), alt0.view(np.uint32))
-        t.join()
-        assert len(got["paths"]) == len(want)
-        for a, b in zip(got["paths"], want):
-            assert bits(a["score"]) == bits(b["score"])
-            assert np.array_equal(a["state_ids"], b["state_ids"]) and np.array_equal(a["seqsizes"], b["seqsizes"])
-        # new reads on the parent: the view follows after a refresh
-        reads2 = [random_seq(rng, n) for n in (61, 150)]
-        engine.set_sequences(reads2)
-        view.refresh_view()
-        wins2 = [(pi, si, 0, len(r)) for pi in range(len(profs)) for si, r in enumerate(reads2)]
-        a, b = view.cost(wins2), engine.cost(wins2)
-        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
-        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
-    finally:
-        view.close()
-
-
 def test_windows_inside_reads_and_ragged_batch(engine, orc):
     """Windows that start mid-read (the t-mers before the window start must not leak in),
     lengths 1..5 (fewer than five emission lengths), and profiles of every Q class in one call."""

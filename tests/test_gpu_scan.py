@@ -78,13 +78,13 @@ def test_sliding_windows_chain_like_test_window(tmp_path, orc):
     want = oracle_scan(orc, read_dcp(DCP), reads, True, False)
     assert rows == want
     assert any(r.split("\t")[1] != "0" for r in rows)  # a hit in a later window
-    # the same with the path pass of a round run AFTER its cost pass instead of beside the next round's
-    # (dcp_scan_run overlaps them on a second engine; a pair with a hit then sits a round out): the same file
-    os.environ["DECIPHON_HIP_OVERLAP"] = "0"
+    # dcp_scan_run scores every pair's no-hit chain in one launch and lets only the pairs that hit walk their real
+    # chains; with nothing speculated -- every pair round by round -- the file is the same
+    os.environ["DECIPHON_HIP_SPECULATE"] = "0"
     try:
-        assert run_scan(str(tmp_path / "serial"), reads) == rows
+        assert run_scan(str(tmp_path / "rounds"), reads) == rows
     finally:
-        del os.environ["DECIPHON_HIP_OVERLAP"]
+        del os.environ["DECIPHON_HIP_SPECULATE"]
 
 
 def test_long_reads_with_error_bearing_domains_like_config5(tmp_path, orc):
