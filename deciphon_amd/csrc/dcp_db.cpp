@@ -374,8 +374,9 @@ void DcpDecoder::prepare()
   size_t const n = nucltp.size() / 4;
   base.resize(n * 4);
   prior.resize(n * 64);
+  static_assert(sizeof(std::atomic<uint8_t>) == 1, "the memo is a byte array");
   memo.reset(new std::atomic<uint8_t>[n * DCP_TABLE_SIZE]);
-  for (size_t i = 0; i < n * DCP_TABLE_SIZE; ++i) memo[i].store(0xFF, std::memory_order_relaxed);
+  memset((void *)memo.get(), 0xFF, n * DCP_TABLE_SIZE); // nobody else sees the decoder yet
   for (size_t i = 0; i < n * 4; ++i) base[i] = exp((double)nucltp[i]);
   for (size_t e = 0; e < n; ++e)
     for (int a = 0; a < 4; ++a)

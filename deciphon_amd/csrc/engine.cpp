@@ -199,6 +199,14 @@ struct dcp_hip
   std::vector<dcp_hip_window> path_wins; // the windows of the last dcp_hip_path
   int path_redone = 0;                   // how many of them needed the literal pass
   DevBuf<uint32_t> d_hits;         // dcp_hip_cost_hits: count, then (window, lrt bits) pairs
+  uint32_t *hits_count = nullptr;  // ... the count on the host (pinned)
+  int hits_pending = -1;           // windows of an outstanding dcp_hip_cost_hits_begin, -1: none
+  struct
+  {
+    std::vector<DcpProblem> problems;
+    std::vector<DcpPack> packs;
+    std::vector<int2> pack_groups;
+  } staged_uploads;                // what the copies of that _begin read
   DevBuf<uint32_t> d_steps, d_compact;
   DevBuf<int64_t> d_step_off, d_compact_off;
   DevBuf<int32_t> d_nsteps;
@@ -362,6 +370,7 @@ void longest_first(DcpProblem *p, size_t n)
 int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Staged &st)
 {
   if (n < 0 || (n > 0 && !w)) return fail(x, DCP_EFUNCUSE, "bad window array");
+  if (x->hits_pending >= 0) return fail(x, DCP_EFUNCUSE, "dcp_hip_cost_hits_begin is outstanding: call dcp_hip_cost_hits_end first");
   if (x->committed != x->profiles.size()) return fail(x, DCP_EFUNCUSE, "profiles not committed");
   int const nseq = (int)x->seq_off.size() - 1;
   int max_s = 1;
@@ -751,6 +760,7 @@ void dcp_hip_del(struct dcp_hip *x)
   }
   if (x->fork_ev) (void)hipEventDestroy(x->fork_ev);
   if (x->stream) (void)hipStreamDestroy(x->stream);
+  if (x->hits_count) (void)hipHostFree(x->hits_count);
   delete x;
 }
 
@@ -1164,24 +1174,45 @@ int dcp_hip_cost(struct dcp_hip *x, int n, struct dcp_hip_window const *w, float
   return 0;
 }
 
-int dcp_hip_cost_hits(struct dcp_hip *x, int n, struct dcp_hip_window const *w, int *nhits, int32_t *hit_window,
-                      float *hit_lrt)
+int dcp_hip_cost_hits_begin(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
 {
-  if (!x || !nhits || (n > 0 && (!hit_window || !hit_lrt))) return DCP_EFUNCUSE;
+  if (!x) return DCP_EFUNCUSE;
+  if (x->hits_pending >= 0) return fail(x, DCP_EFUNCUSE, "dcp_hip_cost_hits_begin twice without dcp_hip_cost_hits_end");
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
-  *nhits = 0;
+  if (!x->hits_count) HIP_TRY(x, hipHostMalloc((void **)&x->hits_count, sizeof(uint32_t), hipHostMallocDefault), DCP_ENOMEM);
   Staged st;
   int rc = stage(x, n, w, ARENA_NONE, st);
   if (rc) return rc;
+  x->hits_pending = n;
   if (n == 0) return 0;
+  x->hits_pending = -1; // until everything is enqueued
   HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   HIP_TRY(x, x->d_hits.reserve(1 + 2 * (size_t)n), DCP_ENOMEM);
   HIP_TRY(x, hipMemsetAsync(x->d_hits.p, 0, sizeof(uint32_t), x->stream), DCP_EFUNCUSE);
   if ((rc = launch_cost_all(x, st))) return rc;
   HIP_TRY(x, dcp_launch_lrt_filter(x->d_out.p, n, x->d_hits.p, x->stream), DCP_EFUNCUSE);
-  uint32_t count = 0;
-  HIP_TRY(x, hipMemcpyAsync(&count, x->d_hits.p, sizeof count, hipMemcpyDeviceToHost, x->stream), DCP_EFUNCUSE);
+  HIP_TRY(x, hipMemcpyAsync(x->hits_count, x->d_hits.p, sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream), DCP_EFUNCUSE);
+  // `st` goes, but the vectors its copies may still be reading live on until the next _begin
+  st.pending = nullptr;
+  x->staged_uploads.problems.swap(st.problems);
+  x->staged_uploads.packs.swap(st.packs);
+  x->staged_uploads.pack_groups.swap(st.pack_groups);
+  x->hits_pending = n;
+  return 0;
+}
+
+int dcp_hip_cost_hits_end(struct dcp_hip *x, int *nhits, int32_t *hit_window, float *hit_lrt)
+{
+  if (!x || !nhits) return DCP_EFUNCUSE;
+  if (x->hits_pending < 0) return fail(x, DCP_EFUNCUSE, "dcp_hip_cost_hits_end without dcp_hip_cost_hits_begin");
+  int const n = x->hits_pending;
+  x->hits_pending = -1;
+  *nhits = 0;
+  if (n == 0) return 0;
+  if (!hit_window || !hit_lrt) return DCP_EFUNCUSE;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  uint32_t const count = *x->hits_count;
   if (count == 0) return 0;
   std::vector<uint32_t> pairs(2 * (size_t)count);
   HIP_TRY(x, hipMemcpyAsync(pairs.data(), x->d_hits.p + 1, pairs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream),
@@ -1197,6 +1228,16 @@ int dcp_hip_cost_hits(struct dcp_hip *x, int n, struct dcp_hip_window const *w, 
   }
   *nhits = (int)count;
   return 0;
+}
+
+int dcp_hip_cost_hits(struct dcp_hip *x, int n, struct dcp_hip_window const *w, int *nhits, int32_t *hit_window,
+                      float *hit_lrt)
+{
+  if (!x || !nhits || (n > 0 && (!hit_window || !hit_lrt))) return DCP_EFUNCUSE;
+  *nhits = 0;
+  int rc = dcp_hip_cost_hits_begin(x, n, w);
+  if (rc) return rc;
+  return dcp_hip_cost_hits_end(x, nhits, hit_window, hit_lrt);
 }
 
 int dcp_hip_cost_bench(struct dcp_hip *x, int n, struct dcp_hip_window const *w, int warmup, int reps, float *ms,

@@ -29,6 +29,7 @@
 #include <string.h>
 #include <deque>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <sys/stat.h>
@@ -65,7 +66,15 @@ struct dcp_scan
   // quasi-codon decoding (c-core/decoder.c): the database stays mapped, and the distributions of a profile are
   // read from it the first time one of its windows yields a hit
   std::unique_ptr<DcpDbReader> db;
-  std::vector<std::shared_ptr<DcpDecoder const>> decoders; // by local profile
+  // a decoder is handed out empty and filled by whichever row-formatting thread needs it first (reading a profile's
+  // distributions and exponentiating them is a fraction of a millisecond -- times hundreds of profiles with hits)
+  struct LazyDecoder
+  {
+    std::once_flag once;
+    int rc = 0;
+    DcpDecoder dec;
+  };
+  std::vector<std::shared_ptr<LazyDecoder>> decoders; // by local profile
 };
 
 struct dcp_press
@@ -249,9 +258,10 @@ int setup_common(dcp_scan *x, char const *dbfile, int device, int index, int npa
   {
     // HBM for the path pass's DP tables, first: VRAM is cleared on allocation, in the background,
     // and the clearing then overlaps the database load and the first cost pass.  Best effort:
-    // dcp_hip_path allocates what it needs anyway.
+    // dcp_hip_path allocates what it needs anyway.  16 GB (never more than a quarter of what is free) hold the
+    // tables of ~8000 hit windows of a median profile at once: the path pass of a scan's first hits is then one slice.
     char const *mb = getenv("DECIPHON_HIP_PATH_BUDGET_MB");
-    (void)dcp_hip_path_reserve(x->eng, mb ? (int64_t)std::max(atol(mb), 1L) << 20 : (int64_t)4 << 30);
+    (void)dcp_hip_path_reserve(x->eng, mb ? (int64_t)std::max(atol(mb), 1L) << 20 : (int64_t)16 << 30);
   }
   if (x->num_proteins > 0)
   {
@@ -350,7 +360,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     float lrt;
     DcpHit hit;
     std::vector<int32_t> ids, sizes;
-    std::shared_ptr<DcpDecoder const> dec;
+    std::shared_ptr<dcp_scan::LazyDecoder> dec;
   };
   std::deque<std::vector<Row>> formatted;
   std::atomic<int> decode_rc{0};
@@ -417,7 +427,6 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     std::vector<PairState> st;
     std::vector<float> spec_lrt; // per speculated window: its lrt when it passed the filter, -1 otherwise
     std::vector<Work> need_cost, need_path;
-    size_t callbacks_due = 0;
 
     if (speculate)
     {
@@ -459,11 +468,17 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
       if (!wins.empty())
       {
         ++rounds;
-        if ((rc = dcp_hip_cost_hits(x->eng, (int)wins.size(), wins.data(), &nh, hit_index.data(), lrts.data())))
+        if ((rc = dcp_hip_cost_hits_begin(x->eng, (int)wins.size(), wins.data())))
+          return raise(rc, __func__, dcp_hip_strerror(x->eng));
+        // while the GPU scores them: one callback per window scored (c-core/thread.c:74).  (A window of a pair that
+        // hit earlier in its chain may turn out not to be the chain's -- it was scored all the same.)
+        spec_lrt.assign(wins.size(), -1.0f);
+        if (x->callback)
+          for (size_t i = 0; i < wins.size() && !x->interrupted; ++i) x->callback(x->userdata);
+        if ((rc = dcp_hip_cost_hits_end(x->eng, &nh, hit_index.data(), lrts.data())))
           return raise(rc, __func__, dcp_hip_strerror(x->eng));
       }
       ph.cost += ph.lap();
-      spec_lrt.assign(wins.size(), -1.0f);
       size_t speculated_of_hit_pairs = 0;
       for (int h = 0; h < nh; ++h) // hit_index ascends: the hits of a pair are neighbours
       {
@@ -476,10 +491,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
         st.push_back(PairState{p, sq, DcpWindow(len, K), chain_of(len, K), base[pi]});
         speculated_of_hit_pairs += base[pi + 1] - base[pi];
       }
-      // the windows of the pairs without a hit are final: one callback each (c-core/thread.c:74); the pairs with a
-      // hit report theirs as their real chains advance
-      nwindows += wins.size() - speculated_of_hit_pairs;
-      callbacks_due = wins.size() - speculated_of_hit_pairs;
+      nwindows += wins.size() - speculated_of_hit_pairs; // the windows of the pairs without a hit are final
     }
     else
     {
@@ -489,9 +501,6 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
             st.push_back(PairState{p, s, DcpWindow((int)batch->seqs[(size_t)s].nt.size(), dcp_hip_profile_core_size(x->eng, p)),
                                    nullptr, 0});
     }
-    if (x->callback)
-      for (size_t i = 0; i < callbacks_due && !x->interrupted; ++i) x->callback(x->userdata);
-
     // moves a pair to its next window that needs work: a path pass (a speculated window that passed the filter) or a
     // cost pass (a window nobody has scored); nothing when its chain has ended
     auto advance = [&](size_t i) {
@@ -499,12 +508,12 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
       while (ps.win.next())
       {
         ++nwindows;
-        if (x->callback) x->callback(x->userdata);
         dcp_hip_window const w{ps.profile, ps.seq, ps.win.start, ps.win.stop};
         bool const as_speculated = ps.spec && (size_t)ps.win.idx < ps.spec->size() &&
                                    (*ps.spec)[(size_t)ps.win.idx] == std::make_pair(ps.win.start, ps.win.stop);
         if (!as_speculated)
         {
+          if (x->callback) x->callback(x->userdata); // a window nobody has scored yet
           need_cost.push_back(Work{i, w, 0.0f});
           return;
         }
@@ -574,12 +583,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
           j.wstart = ps.win.start;
           j.wstop = ps.win.stop;
           j.lrt = batch_p[h].lrt;
-          if (!x->decoders[(size_t)ps.profile]) // decoder_setup, c-core/decoder.c:21-36
-          {
-            auto dec = std::make_shared<DcpDecoder>();
-            if ((rc = x->db->read_decoder(x->index_offset + ps.profile, *dec))) return raise(rc, __func__);
-            x->decoders[(size_t)ps.profile] = dec;
-          }
+          if (!x->decoders[(size_t)ps.profile]) x->decoders[(size_t)ps.profile] = std::make_shared<dcp_scan::LazyDecoder>();
           j.dec = x->decoders[(size_t)ps.profile];
           jobs->push_back(std::move(j));
         }
@@ -596,10 +600,18 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
               {
                 Job const &j = (*jobs)[k];
                 dcp_batch::Seq const &seq = batch->seqs[(size_t)j.seq];
+                dcp_scan::LazyDecoder &ld = *j.dec; // decoder_setup, c-core/decoder.c:21-36, once per profile
+                std::call_once(ld.once, [&]() { ld.rc = scan->db->read_decoder(scan->index_offset + j.profile, ld.dec); });
+                if (ld.rc)
+                {
+                  int expected = 0;
+                  drc->compare_exchange_strong(expected, ld.rc);
+                  continue;
+                }
                 (*out)[k] = Row{j.profile, j.seq, j.widx,
                                 format_row(seq, j.widx, j.wstart, j.wstop, j.hit,
                                            dcp_hip_profile_accession(scan->eng, j.profile), scan->abc_name.c_str(),
-                                           j.lrt, j.ids, j.sizes, *j.dec, drc)};
+                                           j.lrt, j.ids, j.sizes, ld.dec, drc)};
               }
             };
             unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,

@@ -111,6 +111,11 @@ int dcp_hip_cost(struct dcp_hip *, int n, struct dcp_hip_window const *, float *
  * into the window array in increasing order and their lrt; hit_window and hit_lrt must hold n entries. */
 int dcp_hip_cost_hits(struct dcp_hip *, int n, struct dcp_hip_window const *, int *nhits, int32_t *hit_window,
                       float *hit_lrt);
+/* The same in two halves: _begin stages the windows and enqueues the kernels and returns while the GPU works (the
+ * host may do anything meanwhile but call this engine); _end waits and delivers what dcp_hip_cost_hits would.  One
+ * _begin may be outstanding per engine; any other entry point of the engine before its _end is a DCP_EFUNCUSE. */
+int dcp_hip_cost_hits_begin(struct dcp_hip *, int n, struct dcp_hip_window const *);
+int dcp_hip_cost_hits_end(struct dcp_hip *, int *nhits, int32_t *hit_window, float *hit_lrt);
 
 /* viterbi_path + trellis_unzip for n windows (c-core/thread.c:124-126).  Results
  * stay valid until the next dcp_hip_path / dcp_hip_del.
