@@ -12,6 +12,16 @@
 #include "viterbi_kernels.h"
 #include "row_replay.h"
 
+// A device address that reaches a kernel as an INTEGER (the table and checkpoint addresses in DcpProblem::trellis and
+// ckpt_addr[]) would make every access through it a flat_* instruction: the compiler cannot know the address space,
+// flat accesses may complete out of order, and each use of a loaded value then waits for ALL outstanding memory
+// operations -- the emission prefetch of the next row and the stores of this one included (vmcnt(0) twice per row).
+// Going through an address_space(1) pointer tells it the memory is global: global_load / global_store, counted waits.
+template <class T> __device__ __forceinline__ T *dcp_global(uintptr_t address)
+{
+  return (T *)(__attribute__((address_space(1))) T *)address;
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MiB L2 (MI355X_MICROARCH.md, Workgroup
 // dispatch): with the plain blockIdx -> problem mapping the windows of one profile (neighbours in the sorted
 // problem list) land on all eight L2s and every L2 holds the tables of every profile in flight.  This gives
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_ckpt_kernel
   if (dcp_num_blocks(pb.L, B) <= 1) return;
   DcpProfileDev const pf = profiles[pb.profile];
   CostWave<Q, W> w;
-  w.ckpt_out = reinterpret_cast<float *>((uintptr_t)ckpt_addr[pb.out]);
+  w.ckpt_out = dcp_global<float>((uintptr_t)ckpt_addr[pb.out]);
   w.ckpt_every = B;
   w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
   w.run(pb.L, out + 2 * (size_t)pb.out);
@@ -101,11 +111,11 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_store_kerne
   CostWave<Q, W, true> w;
   int const slots = dcp_block_slots(pb.L, B);
   // integer arithmetic: the engine passes arena = 0 and absolute table addresses in pb.trellis
-  w.tab_sp = reinterpret_cast<float *>((uintptr_t)arena + (uintptr_t)pb.trellis);
+  w.tab_sp = dcp_global<float>((uintptr_t)arena + (uintptr_t)pb.trellis);
   w.tab_cells = w.tab_sp + (size_t)slots * DCP_SP_STRIDE;
   w.row_base = block * B;
   if (block > 0)
-    w.ckpt_in = reinterpret_cast<float const *>((uintptr_t)ckpt_addr[pb.out]) + (size_t)(block - 1) * (size_t)dcp_ckpt_floats(pf.Kp, W);
+    w.ckpt_in = dcp_global<float const>((uintptr_t)ckpt_addr[pb.out]) + (size_t)(block - 1) * (size_t)dcp_ckpt_floats(pf.Kp, W);
   w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
   int const last = B > 0 ? (block + 1) * B + 5 : pb.L;
   w.run(pb.L, out + 2 * (size_t)pb.out, last < pb.L ? last : pb.L);
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(64 * W) void dcp_strip_kernel(float const *__restri
     w.ring = ring + (size_t)blockIdx.x * DCP_RING_FLOATS;
     if (STORE)
     {
-      w.tab_sp = reinterpret_cast<float *>((uintptr_t)arena + (uintptr_t)pb.trellis);
+      w.tab_sp = dcp_global<float>((uintptr_t)arena + (uintptr_t)pb.trellis);
       w.tab_cells = w.tab_sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
     }
     w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
@@ -161,13 +171,13 @@ __device__ void dcp_replay_one(float const *__restrict__ pool, DcpProfileDev con
   in.K = pf.K;
   in.Kp = pf.Kp;
   in.L = pb.L;
-  in.sp = reinterpret_cast<float const *>((uintptr_t)table_addr[pb.out]);
+  in.sp = dcp_global<float const>((uintptr_t)table_addr[pb.out]);
   in.cells = in.sp + (size_t)(pb.L + 1) * DCP_SP_STRIDE;
   in.rows = pool + pf.rows_off;
   in.trans = pool + pf.trans_off;
   in.codes = code_rows + pb.code_row;
   in.xt = xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE;
-  float *acc = reinterpret_cast<float *>((uintptr_t)scratch_addr[pb.out]) + (size_t)l * 3 * pf.K;
+  float *acc = dcp_global<float>((uintptr_t)scratch_addr[pb.out]) + (size_t)l * 3 * pf.K;
   dcp_replay_row(in, l, acc, xnodes + l, nodes);
   if (l == pb.L) // T of the last row: the score viterbi_path returns (c-core/viterbi.c:585-586,599)
     out[pb.out] = __builtin_fminf(in.sp[(size_t)l * DCP_SP_STRIDE + 3] + in.xt[DCP_ET],
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(64) void dcp_traceback_kernel(
   in.K = pf.K;
   in.Kp = pf.Kp;
   in.L = pb.L;
-  in.sp = reinterpret_cast<float const *>((uintptr_t)arena + (uintptr_t)pb.trellis);
+  in.sp = dcp_global<float const>((uintptr_t)arena + (uintptr_t)pb.trellis);
   in.cells = in.sp + (size_t)dcp_block_slots(pb.L, B) * DCP_SP_STRIDE;
   in.rows = pool + pf.rows_off;
   in.trans = pool + pf.trans_off;
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_path_blocks_kern
   DcpCodeRow const *codes = code_rows + pb.code_row;
   float const *xt = xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE;
   int const nb = dcp_num_blocks(pb.L, B);
-  float *ckpt = nb > 1 ? reinterpret_cast<float *>((uintptr_t)ckpt_addr[pb.out]) : nullptr;
+  float *ckpt = nb > 1 ? dcp_global<float>((uintptr_t)ckpt_addr[pb.out]) : nullptr;
   if (nb > 1)
   {
     CostWave<Q, W> w;
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_path_blocks_kern
     w.run(pb.L, out + 2 * (size_t)pb.out);
   }
   int const slots = dcp_block_slots(pb.L, B);
-  float *tab_sp = reinterpret_cast<float *>((uintptr_t)pb.trellis);
+  float *tab_sp = dcp_global<float>((uintptr_t)pb.trellis);
   for (int block = nb - 1; block >= 0; --block)
   {
     __syncthreads(); // the checkpoints are written; the walk through the block above has left the table
