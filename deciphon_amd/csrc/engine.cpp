@@ -182,15 +182,38 @@ struct dcp_hip
   int xt_rows = 0;
   std::vector<float> xt_override; // [rows][DCP_XT_STRIDE], dcp_hip_set_xtrans_table
 
-  // problems / results
-  DevBuf<DcpProblem> d_problems;
-  DevBuf<DcpPack> d_packs;         // cost pass: windows of short profiles, several per wavefront
-  DevBuf<int2> d_pack_groups;      // ... and, for four-lane groups, the packs of one profile that share a workgroup
-  DevBuf<float> d_out;
+  // problems / results.  Three sets of window lists and result buffers ("banks"): 0 and 1 for cost passes -- two
+  // batches may be outstanding at once (dcp_hip_cost_hits_begin / _end), the second queued behind the first on the same
+  // kernel streams so that the GPU never drains between them -- and 2 for the path pass, which has its own streams too
+  // (path_set) and may run while cost batches are in flight.  `cur` is the bank the code below works on.
+  struct Bank
+  {
+    DevBuf<DcpProblem> d_problems;
+    DevBuf<DcpPack> d_packs;         // cost pass: windows of short profiles, several per wavefront
+    DevBuf<int2> d_pack_groups;      // ... and, for four-lane groups, the packs of one profile that share a workgroup
+    DevBuf<float> d_out;             // (null, alt) per window
+    DevBuf<uint32_t> d_hits;         // dcp_hip_cost_hits: count, then (window, lrt bits) pairs
+    DevBuf<float> d_ring;            // strip class (K > 4096): the rings of folded rows, one per workgroup in flight
+    uint32_t *hits_count = nullptr;  // the count on the host (pinned)
+    hipEvent_t done_ev = nullptr;    // an outstanding batch: recorded behind its last device operation
+    int n = -1;                      // windows of the outstanding batch, -1: none
+    std::vector<DcpProblem> up_problems; // what the uploads of that batch read
+    std::vector<DcpPack> up_packs;
+    std::vector<int2> up_groups;
+  };
+  Bank bank[3];
+  int cur = 0;
+  int outstanding[2] = {-1, -1}; // banks of the batches begun and not yet ended, oldest first
+  hipStream_t upload_stream = nullptr, fetch_stream = nullptr;
+  // the path pass's own streams and events, swapped with stream / qstream / fork_ev / join_ev for its duration
+  struct StreamSet
+  {
+    hipStream_t stream = nullptr, qstream[DCP_NUM_CLASSES] = {nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[DCP_NUM_CLASSES] = {nullptr};
+  } path_set;
   DevBuf<int64_t> d_aux;           // strip class, literal path pass: table and scratch addresses per window
   DevBuf<int64_t> d_ckpt_addr;     // fast path pass: checkpoint address per window
   DevBuf<DcpTraceState> d_trace;   // fast path pass: where each window's traceback stands between blocks
-  DevBuf<float> d_ring;            // strip class (K > 4096): the rings of folded rows, one per workgroup in flight
   TableArena tables;               // DP tables of the fast path pass
   std::vector<int64_t> table_addr; // per window of the slice being staged (device addresses)
   std::vector<int> path_order;     // fast path pass: request windows, slowest first
@@ -198,15 +221,6 @@ struct dcp_hip
   DevBuf<unsigned char> d_trellis; // trellises of the literal path pass
   std::vector<dcp_hip_window> path_wins; // the windows of the last dcp_hip_path
   int path_redone = 0;                   // how many of them needed the literal pass
-  DevBuf<uint32_t> d_hits;         // dcp_hip_cost_hits: count, then (window, lrt bits) pairs
-  uint32_t *hits_count = nullptr;  // ... the count on the host (pinned)
-  int hits_pending = -1;           // windows of an outstanding dcp_hip_cost_hits_begin, -1: none
-  struct
-  {
-    std::vector<DcpProblem> problems;
-    std::vector<DcpPack> packs;
-    std::vector<int2> pack_groups;
-  } staged_uploads;                // what the copies of that _begin read
   DevBuf<uint32_t> d_steps, d_compact;
   DevBuf<int64_t> d_step_off, d_compact_off;
   DevBuf<int32_t> d_nsteps;
@@ -220,6 +234,8 @@ struct dcp_hip
   double staged_cells = 0;
   int staged_n = -1;
 };
+
+#define BK(x) ((x)->bank[(x)->cur])
 
 namespace
 {
@@ -246,15 +262,16 @@ int ensure_xt(dcp_hip *x, int rows_needed)
 {
   if (!x->mode_set) return fail(x, DCP_EFUNCUSE, "dcp_hip_set_mode has not been called");
   if (rows_needed <= x->xt_rows) return 0;
-  int rows = std::max(rows_needed, 4096);
+  // a window of the scan has at most 100 000 nucleotides (c-core/window.c:13), i.e. 33 333 amino acids: one table
+  // covers them all, so that the table is never replaced while kernels that read it are in flight
+  int rows = std::max(rows_needed, 33336);
   std::vector<float> tab((size_t)rows * DCP_XT_STRIDE, 0.0f);
   for (int s = 1; s < rows; ++s) dcp_xtrans(s, x->multi_hits, x->hmmer3_compat, tab.data() + (size_t)s * DCP_XT_STRIDE);
   if (!x->xt_override.empty())
     memcpy(tab.data(), x->xt_override.data(), std::min(tab.size(), x->xt_override.size()) * sizeof(float));
+  HIP_TRY(x, hipDeviceSynchronize(), DCP_EFUNCUSE); // nothing may still be reading the old table
   HIP_TRY(x, x->d_xt.reserve(tab.size()), DCP_ENOMEM);
-  HIP_TRY(x, hipMemcpyAsync(x->d_xt.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, x->stream),
-          DCP_EFUNCUSE);
-  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  HIP_TRY(x, hipMemcpy(x->d_xt.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice), DCP_EFUNCUSE);
   x->xt_rows = rows;
   return 0;
 }
@@ -367,10 +384,12 @@ void longest_first(DcpProblem *p, size_t n)
 }
 
 // validates windows and builds the device problem list
-int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Staged &st)
+// (origin: the stream the lists are uploaded on -- x->stream unless a batch is begun asynchronously)
+int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Staged &st, hipStream_t origin = nullptr)
 {
+  if (!origin) origin = x->stream;
   if (n < 0 || (n > 0 && !w)) return fail(x, DCP_EFUNCUSE, "bad window array");
-  if (x->hits_pending >= 0) return fail(x, DCP_EFUNCUSE, "dcp_hip_cost_hits_begin is outstanding: call dcp_hip_cost_hits_end first");
+  if (BK(x).n >= 0) return fail(x, DCP_EFUNCUSE, "a dcp_hip_cost_hits_begin is outstanding on these buffers: call dcp_hip_cost_hits_end first");
   if (x->committed != x->profiles.size()) return fail(x, DCP_EFUNCUSE, "profiles not committed");
   int const nseq = (int)x->seq_off.size() - 1;
   int max_s = 1;
@@ -513,26 +532,26 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
   st.c_begin[DCP_NUM_CLASSES] = i;
   if (i != nu) return fail(x, DCP_ELARGECORESIZE, "profile outside every kernel class");
   if (st.c_begin[DCP_STRIP_CLASS + 1] > st.c_begin[DCP_STRIP_CLASS])
-    HIP_TRY(x, x->d_ring.reserve((size_t)DCP_RING_SLOTS * DCP_RING_FLOATS), DCP_ENOMEM);
+    HIP_TRY(x, BK(x).d_ring.reserve((size_t)DCP_RING_SLOTS * DCP_RING_FLOATS), DCP_ENOMEM);
   int rc = ensure_xt(x, max_s + 1);
   if (rc) return rc;
   x->staged_n = -1; // the device problem list is about to be replaced
   // every allocation first: after the first copy is enqueued nothing below can fail but a copy itself
-  HIP_TRY(x, x->d_problems.reserve((size_t)std::max(nu, 1)), DCP_ENOMEM);
-  if (!st.packs.empty()) HIP_TRY(x, x->d_packs.reserve(st.packs.size()), DCP_ENOMEM);
-  if (!st.pack_groups.empty()) HIP_TRY(x, x->d_pack_groups.reserve(st.pack_groups.size()), DCP_ENOMEM);
-  st.pending = x->stream;
+  HIP_TRY(x, BK(x).d_problems.reserve((size_t)std::max(nu, 1)), DCP_ENOMEM);
+  if (!st.packs.empty()) HIP_TRY(x, BK(x).d_packs.reserve(st.packs.size()), DCP_ENOMEM);
+  if (!st.pack_groups.empty()) HIP_TRY(x, BK(x).d_pack_groups.reserve(st.pack_groups.size()), DCP_ENOMEM);
+  st.pending = origin;
   if (nu)
-    HIP_TRY(x, hipMemcpyAsync(x->d_problems.p, st.problems.data(), (size_t)nu * sizeof(DcpProblem),
-                              hipMemcpyHostToDevice, x->stream),
+    HIP_TRY(x, hipMemcpyAsync(BK(x).d_problems.p, st.problems.data(), (size_t)nu * sizeof(DcpProblem),
+                              hipMemcpyHostToDevice, origin),
             DCP_EFUNCUSE);
   if (!st.packs.empty())
-    HIP_TRY(x, hipMemcpyAsync(x->d_packs.p, st.packs.data(), st.packs.size() * sizeof(DcpPack), hipMemcpyHostToDevice,
-                              x->stream),
+    HIP_TRY(x, hipMemcpyAsync(BK(x).d_packs.p, st.packs.data(), st.packs.size() * sizeof(DcpPack), hipMemcpyHostToDevice,
+                              origin),
             DCP_EFUNCUSE);
   if (!st.pack_groups.empty())
-    HIP_TRY(x, hipMemcpyAsync(x->d_pack_groups.p, st.pack_groups.data(), st.pack_groups.size() * sizeof(int2),
-                              hipMemcpyHostToDevice, x->stream),
+    HIP_TRY(x, hipMemcpyAsync(BK(x).d_pack_groups.p, st.pack_groups.data(), st.pack_groups.size() * sizeof(int2),
+                              hipMemcpyHostToDevice, origin),
             DCP_EFUNCUSE);
   return 0;
 }
@@ -542,14 +561,14 @@ DcpLaunch launch_args(dcp_hip *x, Staged const &st, int c)
   DcpLaunch a;
   a.pool = x->d_pool.p;
   a.profiles = x->d_profiles.p;
-  a.problems = x->d_problems.p + st.c_begin[c];
+  a.problems = BK(x).d_problems.p + st.c_begin[c];
   a.code_rows = x->d_rows.p;
   a.xt_table = x->d_xt.p;
-  a.out = x->d_out.p;
+  a.out = BK(x).d_out.p;
   a.arena = x->d_trellis.p;
   a.nprob = st.c_begin[c + 1] - st.c_begin[c];
   a.stream = x->stream;
-  a.ring = x->d_ring.p;
+  a.ring = BK(x).d_ring.p;
   return a;
 }
 
@@ -586,9 +605,14 @@ int launch_all(dcp_hip *x, Staged const &st, bool path)
 // Cost pass.  The packed kernels (short profiles, several windows per wavefront) have one stream per shape.
 // Of the rest, a small launch that mixes single-wave classes goes out as ONE fused kernel (classes 0..3
 // are contiguous in the sorted problem list); large launches keep one kernel per class, which fills the GPU
-// by itself and has its own register budget.  Everything is forked from and joined back into x->stream.
-int launch_cost_all(dcp_hip *x, Staged const &st)
+// by itself and has its own register budget.  Everything is forked from `origin` (the stream the window lists were
+// uploaded on; x->stream by default) and joined into x->stream.
+// reps > 1 (measurement): every kernel `reps` times in its own stream before the join -- the passes of a kernel class
+// follow each other without waiting for the other classes, exactly as the batches of a scan do when a second batch is
+// begun while the first is in flight (dcp_hip_cost_hits_begin): no kernel's tail leaves the GPU idle but the last's.
+int launch_cost_all(dcp_hip *x, Staged const &st, hipStream_t origin = nullptr, int reps = 1)
 {
+  if (!origin) origin = x->stream;
   int const single_wave = st.c_begin[4] - st.c_begin[0];
   int mixed = 0;
   for (int c = 0; c < 4; ++c) mixed += st.c_begin[c + 1] > st.c_begin[c];
@@ -599,8 +623,8 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
   char const *narrow_env = getenv("DECIPHON_HIP_NARROW");
   bool const narrow = !(narrow_env && narrow_env[0] == '0');
   for (int c = 4; narrow && c < DCP_NUM_CLASSES; ++c) kernels += st.c_wide[c] > st.c_begin[c];
-  bool const fork = kernels > 1;
-  if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
+  bool const fork = kernels > 1 || origin != x->stream;
+  if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, origin), DCP_EFUNCUSE);
   // x->stream joins the kernels only after the last launch: a wait is a barrier in x->stream's hardware queue,
   // and a stream that shares that queue would start its kernel behind every barrier issued before
   // (profiles/r02_step_timeline.txt)
@@ -631,7 +655,7 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
         n.stream = x->nstream[c];
         HIP_TRY(x, hipStreamWaitEvent(n.stream, x->fork_ev, 0), DCP_EFUNCUSE);
       }
-      HIP_TRY(x, dcp_launch_cost_narrow(c, n), DCP_EFUNCUSE);
+      for (int r = 0; r < reps; ++r) HIP_TRY(x, dcp_launch_cost_narrow(c, n), DCP_EFUNCUSE);
       if (fork)
       {
         HIP_TRY(x, hipEventRecord(x->njoin_ev[c], n.stream), DCP_EFUNCUSE);
@@ -640,7 +664,8 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
       b.problems += nn;
       b.nprob -= nn;
     }
-    if (b.nprob > 0) HIP_TRY(x, dcp_launch_cost(c, b), DCP_EFUNCUSE);
+    if (b.nprob > 0)
+      for (int r = 0; r < reps; ++r) HIP_TRY(x, dcp_launch_cost(c, b), DCP_EFUNCUSE);
     if (fork)
     {
       HIP_TRY(x, hipEventRecord(x->join_ev[c], b.stream), DCP_EFUNCUSE);
@@ -656,7 +681,7 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
       a.stream = x->qstream[0];
       HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
     }
-    HIP_TRY(x, dcp_launch_cost_fused(a), DCP_EFUNCUSE);
+    for (int r = 0; r < reps; ++r) HIP_TRY(x, dcp_launch_cost_fused(a), DCP_EFUNCUSE);
     if (fork)
     {
       HIP_TRY(x, hipEventRecord(x->join_ev[0], a.stream), DCP_EFUNCUSE);
@@ -674,12 +699,15 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
       HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
     }
     int const ng = st.pg_begin[s + 1] - st.pg_begin[s];
-    if (ng > 0)
-      HIP_TRY(x, dcp_launch_cost_pack_lds(s, a, x->d_packs.p + st.pk_begin[s], x->d_pack_groups.p + st.pg_begin[s], ng,
-                                          (uint32_t)x->row_off.back()),
-              DCP_EFUNCUSE);
-    else
-      HIP_TRY(x, dcp_launch_cost_pack(s, a, x->d_packs.p + st.pk_begin[s], np, (uint32_t)x->row_off.back()), DCP_EFUNCUSE);
+    for (int r = 0; r < reps; ++r)
+    {
+      if (ng > 0)
+        HIP_TRY(x, dcp_launch_cost_pack_lds(s, a, BK(x).d_packs.p + st.pk_begin[s], BK(x).d_pack_groups.p + st.pg_begin[s], ng,
+                                            (uint32_t)x->row_off.back()),
+                DCP_EFUNCUSE);
+      else
+        HIP_TRY(x, dcp_launch_cost_pack(s, a, BK(x).d_packs.p + st.pk_begin[s], np, (uint32_t)x->row_off.back()), DCP_EFUNCUSE);
+    }
     if (fork)
     {
       HIP_TRY(x, hipEventRecord(x->pjoin_ev[s], a.stream), DCP_EFUNCUSE);
@@ -689,6 +717,36 @@ int launch_cost_all(dcp_hip *x, Staged const &st)
   for (hipEvent_t ev : joins) HIP_TRY(x, hipStreamWaitEvent(x->stream, ev, 0), DCP_EFUNCUSE);
   return 0;
 }
+
+// the path pass works on its own bank and streams (see dcp_hip::bank): swapped in for the duration of a call
+struct PathContext
+{
+  dcp_hip *x;
+  int saved_cur;
+  static void swap_streams(dcp_hip *x)
+  {
+    std::swap(x->stream, x->path_set.stream);
+    std::swap(x->fork_ev, x->path_set.fork_ev);
+    for (int c = 0; c < DCP_NUM_CLASSES; ++c)
+    {
+      std::swap(x->qstream[c], x->path_set.qstream[c]);
+      std::swap(x->join_ev[c], x->path_set.join_ev[c]);
+    }
+  }
+  explicit PathContext(dcp_hip *x_) : x(x_), saved_cur(x_->cur)
+  {
+    swap_streams(x);
+    x->cur = 2;
+  }
+  ~PathContext()
+  {
+    swap_streams(x);
+    x->cur = saved_cur;
+  }
+};
+
+// batches begun and not ended
+int outstanding_batches(dcp_hip const *x) { return (x->outstanding[0] >= 0) + (x->outstanding[1] >= 0); }
 
 } // namespace
 
@@ -728,6 +786,24 @@ struct dcp_hip *dcp_hip_new(int device)
     ok = ok && hipStreamCreateWithFlags(&x->nstream[c], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&x->njoin_ev[c], hipEventDisableTiming) == hipSuccess;
   }
+  // the path pass: streams of its own, ahead of the cost kernels' in the hardware's eyes -- its few, long-running
+  // wavefronts are bound by latency, not by issue slots, and slip in beside a cost pass in flight
+  int prio_low = 0, prio_high = 0;
+  ok = ok && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess;
+  ok = ok && hipStreamCreateWithPriority(&x->path_set.stream, hipStreamNonBlocking, prio_high) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&x->path_set.fork_ev, hipEventDisableTiming) == hipSuccess;
+  for (int c = 0; ok && c < DCP_NUM_CLASSES; ++c)
+  {
+    ok = ok && hipStreamCreateWithPriority(&x->path_set.qstream[c], hipStreamNonBlocking, prio_high) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&x->path_set.join_ev[c], hipEventDisableTiming) == hipSuccess;
+  }
+  ok = ok && hipStreamCreateWithFlags(&x->upload_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&x->fetch_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int b = 0; ok && b < 2; ++b)
+  {
+    ok = ok && hipEventCreateWithFlags(&x->bank[b].done_ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&x->bank[b].hits_count, sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  }
   if (!ok)
   {
     dcp_hip_del(x);
@@ -742,11 +818,22 @@ void dcp_hip_del(struct dcp_hip *x)
 {
   if (!x) return;
   (void)hipSetDevice(x->device);
-  if (x->stream) (void)hipStreamSynchronize(x->stream);
+  (void)hipDeviceSynchronize(); // batches begun and never ended included
   for (int c = 0; c < DCP_NUM_CLASSES; ++c)
   {
     if (x->qstream[c]) (void)hipStreamDestroy(x->qstream[c]);
     if (x->join_ev[c]) (void)hipEventDestroy(x->join_ev[c]);
+    if (x->path_set.qstream[c]) (void)hipStreamDestroy(x->path_set.qstream[c]);
+    if (x->path_set.join_ev[c]) (void)hipEventDestroy(x->path_set.join_ev[c]);
+  }
+  if (x->path_set.stream) (void)hipStreamDestroy(x->path_set.stream);
+  if (x->path_set.fork_ev) (void)hipEventDestroy(x->path_set.fork_ev);
+  if (x->upload_stream) (void)hipStreamDestroy(x->upload_stream);
+  if (x->fetch_stream) (void)hipStreamDestroy(x->fetch_stream);
+  for (int b = 0; b < 3; ++b)
+  {
+    if (x->bank[b].done_ev) (void)hipEventDestroy(x->bank[b].done_ev);
+    if (x->bank[b].hits_count) (void)hipHostFree(x->bank[b].hits_count);
   }
   for (int c = 0; c < DCP_NUM_PACK_SHAPES; ++c)
   {
@@ -760,7 +847,6 @@ void dcp_hip_del(struct dcp_hip *x)
   }
   if (x->fork_ev) (void)hipEventDestroy(x->fork_ev);
   if (x->stream) (void)hipStreamDestroy(x->stream);
-  if (x->hits_count) (void)hipHostFree(x->hits_count);
   delete x;
 }
 
@@ -844,6 +930,7 @@ int dcp_hip_add_profile(struct dcp_hip *x, int K, float const *trans, float cons
                         float const *bg_cost, int *index)
 {
   if (!x || !trans || !match || !null_cost || !bg_cost) return DCP_EFUNCUSE;
+  if (outstanding_batches(x)) return fail(x, DCP_EFUNCUSE, "cost batches are outstanding (dcp_hip_cost_hits_begin): end them first");
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   HostProfile hp;
   int rc = describe(x, K, nullptr, hp);
@@ -870,6 +957,7 @@ int dcp_hip_add_protein(struct dcp_hip *x, int K, float const *node_trans, float
                         float const *BMk, float const *null_lprob, float const *bg_lprob, int *index)
 {
   if (!x || !node_trans || !node_emission || !BMk || !null_lprob || !bg_lprob) return DCP_EFUNCUSE;
+  if (outstanding_batches(x)) return fail(x, DCP_EFUNCUSE, "cost batches are outstanding (dcp_hip_cost_hits_begin): end them first");
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   HostProfile hp;
   int rc = describe(x, K, nullptr, hp);
@@ -889,6 +977,7 @@ int dcp_hip_add_protein(struct dcp_hip *x, int K, float const *node_trans, float
 int dcp_hip_load_dcp(struct dcp_hip *x, char const *path, int first, int count)
 {
   if (!x || !path) return DCP_EFUNCUSE;
+  if (outstanding_batches(x)) return fail(x, DCP_EFUNCUSE, "cost batches are outstanding (dcp_hip_cost_hits_begin): end them first");
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   DcpDbReader db;
   int rc = db.open(path);
@@ -1034,6 +1123,7 @@ char const *dcp_hip_profile_accession(struct dcp_hip const *x, int i)
 int dcp_hip_commit_profiles(struct dcp_hip *x)
 {
   if (!x) return DCP_EFUNCUSE;
+  if (outstanding_batches(x)) return fail(x, DCP_EFUNCUSE, "cost batches are outstanding (dcp_hip_cost_hits_begin): end them first");
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   if (x->committed == x->profiles.size()) return 0;
   // the tables are already in HBM; what is published here are the profile descriptors
@@ -1076,6 +1166,7 @@ int dcp_hip_encode(char const *data, int64_t n, uint8_t *out)
 int dcp_hip_set_sequences(struct dcp_hip *x, int nseq, uint8_t const *nt, int64_t const *offsets)
 {
   if (!x || nseq < 0 || !offsets || (nseq > 0 && !nt)) return DCP_EFUNCUSE;
+  if (outstanding_batches(x)) return fail(x, DCP_EFUNCUSE, "cost batches are outstanding (dcp_hip_cost_hits_begin): end them first");
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   x->seq_off.assign(offsets, offsets + nseq + 1);
   x->row_off.resize((size_t)nseq + 1);
@@ -1115,6 +1206,7 @@ int dcp_hip_set_sequences(struct dcp_hip *x, int nseq, uint8_t const *nt, int64_
 int dcp_hip_set_mode(struct dcp_hip *x, int multi_hits, int hmmer3_compat)
 {
   if (!x) return DCP_EFUNCUSE;
+  if (outstanding_batches(x)) return fail(x, DCP_EFUNCUSE, "cost batches are outstanding (dcp_hip_cost_hits_begin): end them first");
   bool mh = multi_hits != 0, h3 = hmmer3_compat != 0;
   if (x->mode_set && (mh != x->multi_hits || h3 != x->hmmer3_compat)) x->xt_rows = 0;
   x->multi_hits = mh;
@@ -1126,6 +1218,7 @@ int dcp_hip_set_mode(struct dcp_hip *x, int multi_hits, int hmmer3_compat)
 int dcp_hip_set_xtrans_table(struct dcp_hip *x, int rows, float const *xt)
 {
   if (!x || rows < 0 || (rows > 0 && !xt)) return DCP_EFUNCUSE;
+  if (outstanding_batches(x)) return fail(x, DCP_EFUNCUSE, "cost batches are outstanding (dcp_hip_cost_hits_begin): end them first");
   x->xt_override.assign((size_t)rows * DCP_XT_STRIDE, 0.0f);
   for (int r = 0; r < rows; ++r)
     memcpy(x->xt_override.data() + (size_t)r * DCP_XT_STRIDE, xt + (size_t)r * DCP_NUM_XTRANS,
@@ -1149,14 +1242,14 @@ int dcp_hip_cost(struct dcp_hip *x, int n, struct dcp_hip_window const *w, float
   int rc = stage(x, n, w, ARENA_NONE, st);
   if (rc) return rc;
   if (n == 0) return 0;
-  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, BK(x).d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   if (timing) (void)hipStreamSynchronize(x->stream);
   auto const t1 = std::chrono::steady_clock::now();
   if ((rc = launch_cost_all(x, st))) return rc;
   if (timing) (void)hipStreamSynchronize(x->stream);
   auto const t2 = std::chrono::steady_clock::now();
   std::vector<float> out(2 * (size_t)n);
-  HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+  HIP_TRY(x, hipMemcpyAsync(out.data(), BK(x).d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
   for (int i = 0; i < n; ++i)
@@ -1177,47 +1270,65 @@ int dcp_hip_cost(struct dcp_hip *x, int n, struct dcp_hip_window const *w, float
 int dcp_hip_cost_hits_begin(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
 {
   if (!x) return DCP_EFUNCUSE;
-  if (x->hits_pending >= 0) return fail(x, DCP_EFUNCUSE, "dcp_hip_cost_hits_begin twice without dcp_hip_cost_hits_end");
+  if (x->outstanding[1] >= 0) return fail(x, DCP_EFUNCUSE, "two batches are outstanding already: call dcp_hip_cost_hits_end first");
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
-  if (!x->hits_count) HIP_TRY(x, hipHostMalloc((void **)&x->hits_count, sizeof(uint32_t), hipHostMallocDefault), DCP_ENOMEM);
+  int const bank = x->outstanding[0] == 0 ? 1 : 0; // the one the batch in flight (if any) does not use
+  x->cur = bank;
+  struct Restore
+  {
+    dcp_hip *x;
+    ~Restore() { x->cur = 0; }
+  } restore{x};
+  dcp_hip::Bank &B = x->bank[bank];
   Staged st;
-  int rc = stage(x, n, w, ARENA_NONE, st);
+  // the lists go up on a stream of their own and the kernels fork from there: a batch begun while another is in
+  // flight is ordered behind it only kernel class by kernel class (the class streams), not as a whole
+  int rc = stage(x, n, w, ARENA_NONE, st, x->upload_stream);
   if (rc) return rc;
-  x->hits_pending = n;
-  if (n == 0) return 0;
-  x->hits_pending = -1; // until everything is enqueued
-  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
-  HIP_TRY(x, x->d_hits.reserve(1 + 2 * (size_t)n), DCP_ENOMEM);
-  HIP_TRY(x, hipMemsetAsync(x->d_hits.p, 0, sizeof(uint32_t), x->stream), DCP_EFUNCUSE);
-  if ((rc = launch_cost_all(x, st))) return rc;
-  HIP_TRY(x, dcp_launch_lrt_filter(x->d_out.p, n, x->d_hits.p, x->stream), DCP_EFUNCUSE);
-  HIP_TRY(x, hipMemcpyAsync(x->hits_count, x->d_hits.p, sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream), DCP_EFUNCUSE);
-  // `st` goes, but the vectors its copies may still be reading live on until the next _begin
+  if (n > 0)
+  {
+    HIP_TRY(x, B.d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+    HIP_TRY(x, B.d_hits.reserve(1 + 2 * (size_t)n), DCP_ENOMEM);
+    HIP_TRY(x, hipMemsetAsync(B.d_hits.p, 0, sizeof(uint32_t), x->upload_stream), DCP_EFUNCUSE);
+    if ((rc = launch_cost_all(x, st, x->upload_stream))) return rc;
+    HIP_TRY(x, dcp_launch_lrt_filter(B.d_out.p, n, B.d_hits.p, x->stream), DCP_EFUNCUSE);
+    HIP_TRY(x, hipMemcpyAsync(B.hits_count, B.d_hits.p, sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream), DCP_EFUNCUSE);
+    HIP_TRY(x, hipEventRecord(B.done_ev, x->stream), DCP_EFUNCUSE);
+  }
+  // `st` goes, but the vectors its uploads may still be reading live on in the bank until the batch is ended
   st.pending = nullptr;
-  x->staged_uploads.problems.swap(st.problems);
-  x->staged_uploads.packs.swap(st.packs);
-  x->staged_uploads.pack_groups.swap(st.pack_groups);
-  x->hits_pending = n;
+  B.up_problems.swap(st.problems);
+  B.up_packs.swap(st.packs);
+  B.up_groups.swap(st.pack_groups);
+  B.n = n;
+  x->outstanding[x->outstanding[0] >= 0 ? 1 : 0] = bank;
   return 0;
 }
 
 int dcp_hip_cost_hits_end(struct dcp_hip *x, int *nhits, int32_t *hit_window, float *hit_lrt)
 {
   if (!x || !nhits) return DCP_EFUNCUSE;
-  if (x->hits_pending < 0) return fail(x, DCP_EFUNCUSE, "dcp_hip_cost_hits_end without dcp_hip_cost_hits_begin");
-  int const n = x->hits_pending;
-  x->hits_pending = -1;
+  int const bank = x->outstanding[0];
+  if (bank < 0) return fail(x, DCP_EFUNCUSE, "dcp_hip_cost_hits_end without dcp_hip_cost_hits_begin");
+  dcp_hip::Bank &B = x->bank[bank];
+  int const n = B.n;
   *nhits = 0;
+  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  // whatever happens below, the batch is over once its device work is
+  hipError_t const waited = n > 0 ? hipEventSynchronize(B.done_ev) : hipSuccess;
+  B.n = -1;
+  x->outstanding[0] = x->outstanding[1];
+  x->outstanding[1] = -1;
+  if (waited != hipSuccess) return fail(x, DCP_EFUNCUSE, "hipEventSynchronize", waited);
   if (n == 0) return 0;
   if (!hit_window || !hit_lrt) return DCP_EFUNCUSE;
-  HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
-  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
-  uint32_t const count = *x->hits_count;
+  uint32_t const count = *B.hits_count;
   if (count == 0) return 0;
   std::vector<uint32_t> pairs(2 * (size_t)count);
-  HIP_TRY(x, hipMemcpyAsync(pairs.data(), x->d_hits.p + 1, pairs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream),
+  // (not on x->stream: a later batch may have work queued there)
+  HIP_TRY(x, hipMemcpyAsync(pairs.data(), B.d_hits.p + 1, pairs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, x->fetch_stream),
           DCP_EFUNCUSE);
-  HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  HIP_TRY(x, hipStreamSynchronize(x->fetch_stream), DCP_EFUNCUSE);
   std::vector<std::pair<uint32_t, uint32_t>> hits(count);
   for (uint32_t i = 0; i < count; ++i) hits[i] = {pairs[2 * (size_t)i], pairs[2 * (size_t)i + 1]};
   std::sort(hits.begin(), hits.end()); // the device appends in no particular order
@@ -1235,6 +1346,7 @@ int dcp_hip_cost_hits(struct dcp_hip *x, int n, struct dcp_hip_window const *w, 
 {
   if (!x || !nhits || (n > 0 && (!hit_window || !hit_lrt))) return DCP_EFUNCUSE;
   *nhits = 0;
+  if (outstanding_batches(x)) return fail(x, DCP_EFUNCUSE, "batches are outstanding: dcp_hip_cost_hits_end first");
   int rc = dcp_hip_cost_hits_begin(x, n, w);
   if (rc) return rc;
   return dcp_hip_cost_hits_end(x, nhits, hit_window, hit_lrt);
@@ -1248,7 +1360,7 @@ int dcp_hip_cost_bench(struct dcp_hip *x, int n, struct dcp_hip_window const *w,
   Staged st;
   int rc = stage(x, n, w, ARENA_NONE, st);
   if (rc) return rc;
-  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, BK(x).d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   for (int i = 0; i < warmup; ++i)
     if ((rc = launch_cost_all(x, st))) return rc;
   hipEvent_t e0, e1;
@@ -1268,7 +1380,7 @@ int dcp_hip_cost_bench(struct dcp_hip *x, int n, struct dcp_hip_window const *w,
   if (null_cost && alt_cost)
   {
     std::vector<float> out(2 * (size_t)n);
-    HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+    HIP_TRY(x, hipMemcpyAsync(out.data(), BK(x).d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
             DCP_EFUNCUSE);
     HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
     for (int i = 0; i < n; ++i)
@@ -1287,7 +1399,7 @@ int dcp_hip_stage(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
   Staged st;
   int rc = stage(x, n, w, ARENA_NONE, st);
   if (rc) return rc;
-  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, BK(x).d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
   memcpy(x->staged_c_begin, st.c_begin, sizeof(st.c_begin));
   memcpy(x->staged_c_wide, st.c_wide, sizeof(st.c_wide));
@@ -1311,8 +1423,14 @@ int dcp_hip_run_staged(struct dcp_hip *x, int reps, float *ms, double *cells)
   HIP_TRY(x, hipEventCreate(&e0), DCP_EFUNCUSE);
   HIP_TRY(x, hipEventCreate(&e1), DCP_EFUNCUSE);
   HIP_TRY(x, hipEventRecord(e0, x->stream), DCP_EFUNCUSE);
+  // the passes as the batches of a scan follow each other (dcp_hip_cost_hits_begin while another batch is in flight):
+  // kernel class by kernel class, not pass by pass.  DECIPHON_HIP_STEP_JOIN=1: every pass joined before the next starts.
+  char const *join_env = getenv("DECIPHON_HIP_STEP_JOIN");
   int rc = 0;
-  for (int i = 0; i < reps && !rc; ++i) rc = launch_cost_all(x, st);
+  if (join_env && join_env[0] == '1')
+    for (int i = 0; i < reps && !rc; ++i) rc = launch_cost_all(x, st);
+  else if (reps > 0)
+    rc = launch_cost_all(x, st, nullptr, reps);
   if (rc) return rc;
   HIP_TRY(x, hipEventRecord(e1, x->stream), DCP_EFUNCUSE);
   HIP_TRY(x, hipEventSynchronize(e1), DCP_EFUNCUSE);
@@ -1330,7 +1448,7 @@ int dcp_hip_fetch_staged(struct dcp_hip *x, float *null_cost, float *alt_cost)
   if (!x || x->staged_n <= 0 || !null_cost || !alt_cost) return DCP_EFUNCUSE;
   size_t const n = (size_t)x->staged_n;
   std::vector<float> out(2 * n);
-  HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+  HIP_TRY(x, hipMemcpyAsync(out.data(), BK(x).d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
   for (size_t i = 0; i < n; ++i)
@@ -1457,7 +1575,7 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
       Staged ss;
       int rc0 = stage(x, (int)ws.size(), ws.data(), ARENA_TABLE, ss);
       if (rc0) return rc0;
-      HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+      HIP_TRY(x, BK(x).d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
       DcpLaunch a = launch_args(x, ss, DCP_STRIP_CLASS);
       a.arena = nullptr;
       HIP_TRY(x, dcp_launch_cost_store(DCP_STRIP_CLASS, a, nullptr, 0, 0), DCP_EFUNCUSE);
@@ -1466,7 +1584,7 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
   Staged st;
   int rc = stage(x, n, w.data(), ARENA_TRELLIS, st);
   if (rc) return rc;
-  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, BK(x).d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   HIP_TRY(x, x->d_trellis.reserve(st.arena_bytes), DCP_ENOMEM);
   if ((rc = launch_all(x, st, true))) return rc;
   if (max_rows > 0) // step 2 for the strip class: the rows of every such window side by side
@@ -1491,7 +1609,7 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
           DCP_EFUNCUSE);
   {
     DcpLaunch a = launch_args(x, st, 0);
-    a.problems = x->d_problems.p;
+    a.problems = BK(x).d_problems.p;
     a.nprob = n;
     HIP_TRY(x, dcp_launch_unzip(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p), DCP_EFUNCUSE);
   }
@@ -1499,7 +1617,7 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
   std::vector<int32_t> nsteps;
   std::vector<int64_t> compact;
   std::vector<uint32_t> steps;
-  HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+  HIP_TRY(x, hipMemcpyAsync(out.data(), BK(x).d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
   if ((rc = fetch_steps(x, n, nsteps, compact, steps))) return rc;
   // every earlier trellis offset pointed into the arena that was just rewritten
@@ -1566,7 +1684,7 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
   int rc = stage(x, n, x->path_sorted.data() + b, ARENA_TABLE, st);
   if (rc) return rc;
   tm.lap("stage");
-  HIP_TRY(x, x->d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  HIP_TRY(x, BK(x).d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   int const B = ckpt_rows();
   // checkpoints sit behind each window's block table (dcp_hip_path placed fast_bytes per window)
   std::vector<int64_t> ckpt_addr((size_t)n, 0);
@@ -1647,7 +1765,7 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
   std::vector<int32_t> nsteps;
   std::vector<int64_t> compact;
   std::vector<uint32_t> steps;
-  HIP_TRY(x, hipMemcpyAsync(out.data(), x->d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+  HIP_TRY(x, hipMemcpyAsync(out.data(), BK(x).d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
   if ((rc = fetch_steps(x, n, nsteps, compact, steps))) return rc;
   tm.lap("fetch");
@@ -1698,6 +1816,7 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
 {
   if (!x || n < 0 || (n > 0 && !w)) return DCP_EFUNCUSE;
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  PathContext ctx(x); // its own window lists, result buffers and streams: cost batches may be in flight
   x->paths.clear();
   x->path_wins.assign(w, w + n);
   x->paths.resize((size_t)n);
@@ -1807,6 +1926,7 @@ int dcp_hip_path_trellis(struct dcp_hip const *cx, int i, uint32_t const **xnode
   dcp_hip *x = const_cast<dcp_hip *>(cx);
   if (!x || i < 0 || i >= (int)x->paths.size() || !xnodes || !nodes) return DCP_EFUNCUSE;
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
+  PathContext ctx(x);
   if (!x->paths[(size_t)i].has_trellis)
   {
     // The fast path pass keeps no trellis.  Somebody wants one: run the literal pass for the

@@ -383,18 +383,17 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   int const nprof = dcp_hip_num_profiles(x->eng);
   // Windows of ONE (profile, read) pair form a chain -- where window w + 1 starts depends on the hit of window w
   // (c-core/window.c:21-31, c-core/thread.c:162) -- but hits are rare, and while a pair has had none its chain is the
-  // same for every pair with that read length and core size.  So a chunk of profiles is scored SPECULATIVELY: every
-  // window of every pair's no-hit chain in one launch (cost pass + LRT filter on the device, c-core/thread.c:114-121).
-  // Pairs without a hit are done.  A pair with hits then walks its real chain: the path pass of its first hit
-  // (c-core/thread.c:123-166) sets last_hit_pos; while the windows that follow are still the speculated ones their
-  // scores stand, otherwise they are scored again -- in rounds over the few pairs concerned, the path passes of a
-  // round in one call.  Rows are emitted in the reference's order (profile, read, window) whatever the order of work.
+  // same for every pair with that read length and core size.  So the profiles are scored SPECULATIVELY, chunk by
+  // chunk: every window of every pair's no-hit chain in one batch (cost pass + LRT filter on the device,
+  // c-core/thread.c:114-121).  Two batches are kept in flight (dcp_hip_cost_hits_begin): while the GPU scores chunks
+  // c + 1 and c + 2 the host takes the hits of chunk c through the path pass (c-core/thread.c:123-166: viterbi_path,
+  // trellis_unzip, hit span, last_hit_pos; on streams of its own, beside the cost kernels) and formats their rows.
+  // Pairs without a hit are done.  A pair with hits walks its real chain: while the windows that follow a hit are
+  // still the speculated ones their scores stand, otherwise they are scored again -- in a few small rounds at the end.
+  // Rows are emitted in the reference's order (profile, read, window) whatever the order of work.
   // DECIPHON_HIP_SPECULATE=0: nothing is assumed, every pair goes round by round (the tests compare the two).
   char const *spec_env = getenv("DECIPHON_HIP_SPECULATE");
   bool const speculate = !(spec_env && spec_env[0] == '0');
-  // profiles are walked in chunks so that the window table stays small
-  size_t const max_pairs = 1u << 21;
-  int chunk = nseq > 0 ? (int)std::max<size_t>(1, max_pairs / (size_t)nseq) : nprof;
   typedef std::vector<std::pair<int, int>> Chain; // [start, stop) of the windows of a pair that never hits
   std::map<std::pair<int, int>, Chain> chains;    // by (read length, core size)
   auto chain_of = [&](int seq_size, int core_size) -> Chain const * {
@@ -408,31 +407,202 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     }
     return &it->second;
   };
-  for (int p0 = 0; p0 < nprof && !x->interrupted; p0 += chunk)
+  // chunks of profiles: small enough for the window table of a chunk (2^21 pairs), and -- when the scan is large --
+  // about 1e11 DP cells each (~0.1 s of cost pass: a few times what a path pass takes, so that the two batches in
+  // flight outlast the host's work on the chunk before them)
+  std::vector<std::pair<int, int>> chunks;
   {
-    int const p1 = std::min(nprof, p0 + chunk);
-    struct PairState
+    double read_nt = 0;
+    for (dcp_batch::Seq const &sq : batch->seqs) read_nt += (double)sq.nt.size();
+    size_t const max_pairs = 1u << 21;
+    int const by_pairs = nseq > 0 ? (int)std::max<size_t>(1, max_pairs / (size_t)nseq) : std::max(nprof, 1);
+    char const *cells_env = getenv("DECIPHON_HIP_CHUNK_CELLS");
+    double const chunk_cells = cells_env ? atof(cells_env) : 1.0e11;
+    for (int p0 = 0; p0 < nprof;)
     {
-      int profile, seq;
-      DcpWindow win;
-      Chain const *spec; // the speculated chain, scores at spec_lrt[base ..]; nullptr: nothing speculated
-      size_t base;
-    };
-    struct Work
-    {
-      size_t pair;
-      dcp_hip_window w;
-      float lrt;
-    };
-    std::vector<PairState> st;
-    std::vector<float> spec_lrt; // per speculated window: its lrt when it passed the filter, -1 otherwise
-    std::vector<Work> need_cost, need_path;
+      int p1 = p0;
+      double cells = 0;
+      while (p1 < nprof && p1 - p0 < by_pairs && (p1 == p0 || cells < chunk_cells))
+        cells += read_nt * (double)dcp_hip_profile_core_size(x->eng, p1++);
+      chunks.emplace_back(p0, p1);
+      p0 = p1;
+    }
+  }
+  struct PairState
+  {
+    int profile, seq;
+    DcpWindow win;
+    Chain const *spec;     // the speculated chain, nullptr: nothing speculated
+    float const *spec_lrt; // ... and per window of it: its lrt when it passed the filter, -1 otherwise
+  };
+  struct Work
+  {
+    size_t pair;
+    dcp_hip_window w;
+    float lrt;
+  };
+  std::deque<PairState> st;                // pairs that need more than their speculated scores
+  std::deque<std::vector<float>> spec_store; // spec_lrt of every chunk: alive until the last pair is done
+  std::vector<Work> need_cost, need_path;
 
-    if (speculate)
+  // moves a pair to its next window that needs work: a path pass (a speculated window that passed the filter) or a
+  // cost pass (a window nobody has scored); nothing when its chain has ended
+  auto advance = [&](size_t i) {
+    PairState &ps = st[i];
+    while (ps.win.next())
     {
+      ++nwindows;
+      dcp_hip_window const w{ps.profile, ps.seq, ps.win.start, ps.win.stop};
+      bool const as_speculated = ps.spec && (size_t)ps.win.idx < ps.spec->size() &&
+                                 (*ps.spec)[(size_t)ps.win.idx] == std::make_pair(ps.win.start, ps.win.stop);
+      if (!as_speculated)
+      {
+        if (x->callback) x->callback(x->userdata); // a window nobody has scored yet
+        need_cost.push_back(Work{i, w, 0.0f});
+        return;
+      }
+      float const lrt = ps.spec_lrt[ps.win.idx];
+      if (lrt >= 0.0f)
+      {
+        need_path.push_back(Work{i, w, lrt});
+        return;
+      }
+    }
+  };
+
+  // c-core/thread.c:123-166 for a batch of windows that passed the filter: viterbi_path, trellis_unzip, the hit span,
+  // last_hit_pos; their rows go to the formatter threads; their pairs move on
+  auto run_path_batch = [&]() -> int {
+    std::vector<Work> batch_p;
+    batch_p.swap(need_path);
+    std::vector<dcp_hip_window> hits(batch_p.size());
+    for (size_t k = 0; k < batch_p.size(); ++k) hits[k] = batch_p[k].w;
+    nhits += hits.size();
+    ph.windows += ph.lap();
+    int prc = dcp_hip_path(x->eng, (int)hits.size(), hits.data());
+    if (prc) return raise(prc, __func__, dcp_hip_strerror(x->eng));
+    ph.path += ph.lap();
+    // hit spans first (they move the window chains); the rows are then formatted by up to 16 host threads (a row
+    // is a few thousand short appends) while the GPU goes on
+    auto jobs = std::make_shared<std::vector<Job>>();
+    for (size_t h = 0; h < batch_p.size(); ++h)
+    {
+      int const n = dcp_hip_path_nsteps(x->eng, (int)h);
+      Job j;
+      j.ids.resize((size_t)n);
+      j.sizes.resize((size_t)n);
+      if ((prc = dcp_hip_path_steps(x->eng, (int)h, j.ids.data(), j.sizes.data()))) return raise(prc, __func__);
+      if (!dcp_find_hit(j.ids, j.sizes, j.hit)) continue;
+      PairState &ps = st[batch_p[h].pair];
+      ps.win.last_hit_pos = j.hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
+      j.profile = ps.profile;
+      j.seq = ps.seq;
+      j.widx = ps.win.idx;
+      j.wstart = ps.win.start;
+      j.wstop = ps.win.stop;
+      j.lrt = batch_p[h].lrt;
+      if (!x->decoders[(size_t)ps.profile]) x->decoders[(size_t)ps.profile] = std::make_shared<dcp_scan::LazyDecoder>();
+      j.dec = x->decoders[(size_t)ps.profile];
+      jobs->push_back(std::move(j));
+    }
+    if (!jobs->empty())
+    {
+      formatted.emplace_back(jobs->size());
+      std::vector<Row> *out = &formatted.back();
+      dcp_scan const *scan = x;
+      std::atomic<int> *drc = &decode_rc;
+      formatters.add(std::thread([jobs, out, scan, batch, drc]() {
+        std::atomic<size_t> next_job{0};
+        auto work = [&]() {
+          for (size_t k = next_job.fetch_add(1); k < jobs->size(); k = next_job.fetch_add(1))
+          {
+            Job const &j = (*jobs)[k];
+            dcp_batch::Seq const &seq = batch->seqs[(size_t)j.seq];
+            dcp_scan::LazyDecoder &ld = *j.dec; // decoder_setup, c-core/decoder.c:21-36, once per profile
+            std::call_once(ld.once, [&]() { ld.rc = scan->db->read_decoder(scan->index_offset + j.profile, ld.dec); });
+            if (ld.rc)
+            {
+              int expected = 0;
+              drc->compare_exchange_strong(expected, ld.rc);
+              continue;
+            }
+            (*out)[k] = Row{j.profile, j.seq, j.widx,
+                            format_row(seq, j.widx, j.wstart, j.wstop, j.hit,
+                                       dcp_hip_profile_accession(scan->eng, j.profile), scan->abc_name.c_str(),
+                                       j.lrt, j.ids, j.sizes, ld.dec, drc)};
+          }
+        };
+        unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
+                                                      (unsigned)std::max<size_t>(jobs->size() / 8, 1)});
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+      }));
+    }
+    ph.rows += ph.lap();
+    for (Work const &wk : batch_p) advance(wk.pair);
+    ph.windows += ph.lap();
+    return 0;
+  };
+
+  // c-core/thread.c:114-121 for windows nobody has scored yet (only with no batch in flight)
+  auto run_cost_batch = [&]() -> int {
+    std::vector<Work> batch_c;
+    batch_c.swap(need_cost);
+    std::vector<dcp_hip_window> wins(batch_c.size());
+    for (size_t k = 0; k < batch_c.size(); ++k) wins[k] = batch_c[k].w;
+    std::vector<int32_t> hit_index(wins.size());
+    std::vector<float> lrts(wins.size());
+    int nh = 0;
+    ++rounds;
+    ph.windows += ph.lap();
+    int crc = dcp_hip_cost_hits(x->eng, (int)wins.size(), wins.data(), &nh, hit_index.data(), lrts.data());
+    if (crc) return raise(crc, __func__, dcp_hip_strerror(x->eng));
+    ph.cost += ph.lap();
+    std::vector<char> is_hit(wins.size(), 0);
+    for (int h = 0; h < nh; ++h)
+    {
+      size_t const k = (size_t)hit_index[(size_t)h];
+      is_hit[k] = 1;
+      need_path.push_back(Work{batch_c[k].pair, batch_c[k].w, lrts[(size_t)h]});
+    }
+    for (size_t k = 0; k < batch_c.size(); ++k)
+      if (!is_hit[k]) advance(batch_c[k].pair);
+    ph.windows += ph.lap();
+    return 0;
+  };
+
+  if (speculate)
+  {
+    struct InFlight
+    {
+      int chunk;
       std::vector<dcp_hip_window> wins;
       std::vector<size_t> base; // first window of pair (p - p0) * nseq + s
-      base.reserve((size_t)(p1 - p0) * (size_t)nseq + 1);
+    };
+    std::deque<InFlight> flight;
+    // whatever happens, no batch stays outstanding on the engine
+    struct Drain
+    {
+      dcp_hip *eng;
+      std::deque<InFlight> *flight;
+      ~Drain()
+      {
+        int nh = 0;
+        for (InFlight &f : *flight)
+        {
+          std::vector<int32_t> hw(f.wins.size() + 1);
+          std::vector<float> hl(f.wins.size() + 1);
+          (void)dcp_hip_cost_hits_end(eng, &nh, hw.data(), hl.data());
+        }
+      }
+    } drain{x->eng, &flight};
+    auto begin_chunk = [&](int c) -> int {
+      int const p0 = chunks[(size_t)c].first, p1 = chunks[(size_t)c].second;
+      InFlight f;
+      f.chunk = c;
+      f.base.reserve((size_t)(p1 - p0) * (size_t)nseq + 1);
       for (int pass = 0; pass < 2; ++pass) // count, then fill
       {
         size_t n = 0;
@@ -448,190 +618,95 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
             if (len == 0) last_len = 0;
             if (pass == 1)
             {
-              base.push_back(n);
+              f.base.push_back(n);
               if (ch)
               {
-                dcp_hip_window *w = wins.data() + n;
+                dcp_hip_window *w = f.wins.data() + n;
                 for (std::pair<int, int> const &r : *ch) *w++ = dcp_hip_window{p, s, r.first, r.second};
               }
             }
             n += ch ? ch->size() : 0;
           }
         }
-        if (pass == 0) wins.resize(n);
+        if (pass == 0) f.wins.resize(n);
       }
-      base.push_back(wins.size());
+      f.base.push_back(f.wins.size());
       ph.windows += ph.lap();
-      std::vector<int32_t> hit_index(wins.size());
-      std::vector<float> lrts(wins.size());
-      int nh = 0;
-      if (!wins.empty())
-      {
-        ++rounds;
-        if ((rc = dcp_hip_cost_hits_begin(x->eng, (int)wins.size(), wins.data())))
-          return raise(rc, __func__, dcp_hip_strerror(x->eng));
-        // while the GPU scores them: one callback per window scored (c-core/thread.c:74).  (A window of a pair that
-        // hit earlier in its chain may turn out not to be the chain's -- it was scored all the same.)
-        spec_lrt.assign(wins.size(), -1.0f);
-        if (x->callback)
-          for (size_t i = 0; i < wins.size() && !x->interrupted; ++i) x->callback(x->userdata);
-        if ((rc = dcp_hip_cost_hits_end(x->eng, &nh, hit_index.data(), lrts.data())))
-          return raise(rc, __func__, dcp_hip_strerror(x->eng));
-      }
+      ++rounds;
+      int brc = dcp_hip_cost_hits_begin(x->eng, (int)f.wins.size(), f.wins.data());
+      if (brc) return raise(brc, __func__, dcp_hip_strerror(x->eng));
+      size_t const nw = f.wins.size();
+      flight.push_back(std::move(f));
+      // while the GPU scores them: one callback per window scored (c-core/thread.c:74).  (A window of a pair that
+      // hit earlier in its chain may turn out not to be the chain's -- it was scored all the same.)
+      if (x->callback)
+        for (size_t i = 0; i < nw && !x->interrupted; ++i) x->callback(x->userdata);
       ph.cost += ph.lap();
-      size_t speculated_of_hit_pairs = 0;
+      return 0;
+    };
+    int next = 0;
+    int const nchunks = (int)chunks.size();
+    while (next < nchunks && flight.size() < 2 && !x->interrupted)
+      if ((rc = begin_chunk(next++))) return rc;
+    while (!flight.empty())
+    {
+      InFlight f = std::move(flight.front());
+      flight.pop_front();
+      int const p0 = chunks[(size_t)f.chunk].first, p1 = chunks[(size_t)f.chunk].second;
+      std::vector<int32_t> hit_index(f.wins.size() + 1);
+      std::vector<float> lrts(f.wins.size() + 1);
+      int nh = 0;
+      if ((rc = dcp_hip_cost_hits_end(x->eng, &nh, hit_index.data(), lrts.data())))
+        return raise(rc, __func__, dcp_hip_strerror(x->eng));
+      ph.cost += ph.lap();
+      if (x->interrupted) continue; // (the batches still in flight are ended and dropped)
+      if (next < nchunks && (rc = begin_chunk(next++))) return rc;
+      spec_store.emplace_back(f.wins.size(), -1.0f);
+      std::vector<float> &spec_lrt = spec_store.back();
+      size_t speculated_of_hit_pairs = 0, first_new = st.size();
+      size_t last_pi = (size_t)-1;
       for (int h = 0; h < nh; ++h) // hit_index ascends: the hits of a pair are neighbours
       {
         size_t const wi = (size_t)hit_index[(size_t)h];
         spec_lrt[wi] = lrts[(size_t)h];
-        size_t const pi = (size_t)(std::upper_bound(base.begin(), base.end(), wi) - base.begin()) - 1;
-        if (!st.empty() && st.back().base == base[pi]) continue;
+        size_t const pi = (size_t)(std::upper_bound(f.base.begin(), f.base.end(), wi) - f.base.begin()) - 1;
+        if (pi == last_pi) continue;
+        last_pi = pi;
         int const p = p0 + (int)(pi / (size_t)nseq), sq = (int)(pi % (size_t)nseq);
         int const len = (int)batch->seqs[(size_t)sq].nt.size(), K = dcp_hip_profile_core_size(x->eng, p);
-        st.push_back(PairState{p, sq, DcpWindow(len, K), chain_of(len, K), base[pi]});
-        speculated_of_hit_pairs += base[pi + 1] - base[pi];
+        st.push_back(PairState{p, sq, DcpWindow(len, K), chain_of(len, K), spec_lrt.data() + f.base[pi]});
+        speculated_of_hit_pairs += f.base[pi + 1] - f.base[pi];
       }
-      nwindows += wins.size() - speculated_of_hit_pairs; // the windows of the pairs without a hit are final
+      nwindows += f.wins.size() - speculated_of_hit_pairs; // the windows of the pairs without a hit are final
+      for (size_t i = first_new; i < st.size(); ++i) advance(i);
+      ph.windows += ph.lap();
+      // the path passes of this chunk's hits, beside the batches in flight; what needs scoring again waits for the end
+      while (!need_path.empty() && !x->interrupted)
+        if ((rc = run_path_batch())) return rc;
+      // the decoders of this chunk's profiles go with the chunk once its rows are under way (a memo of (K + 3) * 1364
+      // bytes each; the formatter jobs hold their own references): a Pfam-sized database with hits on most profiles
+      // would pin gigabytes.  (A pair of this chunk that hits again in the final rounds makes a new one.)
+      for (int p = p0; p < p1; ++p) x->decoders[(size_t)p].reset();
+      x->done_proteins += p1 - p0;
     }
-    else
-    {
-      for (int p = p0; p < p1; ++p)
-        for (int s = 0; s < nseq; ++s)
-          if (!batch->seqs[(size_t)s].nt.empty())
-            st.push_back(PairState{p, s, DcpWindow((int)batch->seqs[(size_t)s].nt.size(), dcp_hip_profile_core_size(x->eng, p)),
-                                   nullptr, 0});
-    }
-    // moves a pair to its next window that needs work: a path pass (a speculated window that passed the filter) or a
-    // cost pass (a window nobody has scored); nothing when its chain has ended
-    auto advance = [&](size_t i) {
-      PairState &ps = st[i];
-      while (ps.win.next())
-      {
-        ++nwindows;
-        dcp_hip_window const w{ps.profile, ps.seq, ps.win.start, ps.win.stop};
-        bool const as_speculated = ps.spec && (size_t)ps.win.idx < ps.spec->size() &&
-                                   (*ps.spec)[(size_t)ps.win.idx] == std::make_pair(ps.win.start, ps.win.stop);
-        if (!as_speculated)
-        {
-          if (x->callback) x->callback(x->userdata); // a window nobody has scored yet
-          need_cost.push_back(Work{i, w, 0.0f});
-          return;
-        }
-        float const lrt = spec_lrt[ps.base + (size_t)ps.win.idx];
-        if (lrt >= 0.0f)
-        {
-          need_path.push_back(Work{i, w, lrt});
-          return;
-        }
-      }
-    };
-    for (size_t i = 0; i < st.size(); ++i) advance(i);
-    ph.windows += ph.lap();
-
-    while ((!need_cost.empty() || !need_path.empty()) && !x->interrupted)
-    {
-      if (!need_cost.empty()) // c-core/thread.c:114-121 for the windows nobody has scored yet
-      {
-        std::vector<Work> batch_c;
-        batch_c.swap(need_cost);
-        std::vector<dcp_hip_window> wins(batch_c.size());
-        for (size_t k = 0; k < batch_c.size(); ++k) wins[k] = batch_c[k].w;
-        std::vector<int32_t> hit_index(wins.size());
-        std::vector<float> lrts(wins.size());
-        int nh = 0;
-        ++rounds;
-        ph.windows += ph.lap();
-        if ((rc = dcp_hip_cost_hits(x->eng, (int)wins.size(), wins.data(), &nh, hit_index.data(), lrts.data())))
-          return raise(rc, __func__, dcp_hip_strerror(x->eng));
-        ph.cost += ph.lap();
-        std::vector<char> is_hit(wins.size(), 0);
-        for (int h = 0; h < nh; ++h)
-        {
-          size_t const k = (size_t)hit_index[(size_t)h];
-          is_hit[k] = 1;
-          need_path.push_back(Work{batch_c[k].pair, batch_c[k].w, lrts[(size_t)h]});
-        }
-        for (size_t k = 0; k < batch_c.size(); ++k)
-          if (!is_hit[k]) advance(batch_c[k].pair);
-        ph.windows += ph.lap();
-      }
-      if (!need_path.empty()) // c-core/thread.c:123-166: viterbi_path, trellis_unzip, the hit span, last_hit_pos
-      {
-        std::vector<Work> batch_p;
-        batch_p.swap(need_path);
-        std::vector<dcp_hip_window> hits(batch_p.size());
-        for (size_t k = 0; k < batch_p.size(); ++k) hits[k] = batch_p[k].w;
-        nhits += hits.size();
-        if ((rc = dcp_hip_path(x->eng, (int)hits.size(), hits.data()))) return raise(rc, __func__, dcp_hip_strerror(x->eng));
-        ph.path += ph.lap();
-        // hit spans first (they move the window chains); the rows are then formatted by up to 16 host threads (a row
-        // is a few thousand short appends) while the GPU goes on
-        auto jobs = std::make_shared<std::vector<Job>>();
-        for (size_t h = 0; h < batch_p.size(); ++h)
-        {
-          int const n = dcp_hip_path_nsteps(x->eng, (int)h);
-          Job j;
-          j.ids.resize((size_t)n);
-          j.sizes.resize((size_t)n);
-          if ((rc = dcp_hip_path_steps(x->eng, (int)h, j.ids.data(), j.sizes.data()))) return raise(rc, __func__);
-          if (!dcp_find_hit(j.ids, j.sizes, j.hit)) continue;
-          PairState &ps = st[batch_p[h].pair];
-          ps.win.last_hit_pos = j.hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
-          j.profile = ps.profile;
-          j.seq = ps.seq;
-          j.widx = ps.win.idx;
-          j.wstart = ps.win.start;
-          j.wstop = ps.win.stop;
-          j.lrt = batch_p[h].lrt;
-          if (!x->decoders[(size_t)ps.profile]) x->decoders[(size_t)ps.profile] = std::make_shared<dcp_scan::LazyDecoder>();
-          j.dec = x->decoders[(size_t)ps.profile];
-          jobs->push_back(std::move(j));
-        }
-        if (!jobs->empty())
-        {
-          formatted.emplace_back(jobs->size());
-          std::vector<Row> *out = &formatted.back();
-          dcp_scan const *scan = x;
-          std::atomic<int> *drc = &decode_rc;
-          formatters.add(std::thread([jobs, out, scan, batch, drc]() {
-            std::atomic<size_t> next_job{0};
-            auto work = [&]() {
-              for (size_t k = next_job.fetch_add(1); k < jobs->size(); k = next_job.fetch_add(1))
-              {
-                Job const &j = (*jobs)[k];
-                dcp_batch::Seq const &seq = batch->seqs[(size_t)j.seq];
-                dcp_scan::LazyDecoder &ld = *j.dec; // decoder_setup, c-core/decoder.c:21-36, once per profile
-                std::call_once(ld.once, [&]() { ld.rc = scan->db->read_decoder(scan->index_offset + j.profile, ld.dec); });
-                if (ld.rc)
-                {
-                  int expected = 0;
-                  drc->compare_exchange_strong(expected, ld.rc);
-                  continue;
-                }
-                (*out)[k] = Row{j.profile, j.seq, j.widx,
-                                format_row(seq, j.widx, j.wstart, j.wstop, j.hit,
-                                           dcp_hip_profile_accession(scan->eng, j.profile), scan->abc_name.c_str(),
-                                           j.lrt, j.ids, j.sizes, ld.dec, drc)};
-              }
-            };
-            unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
-                                                          (unsigned)std::max<size_t>(jobs->size() / 8, 1)});
-            std::vector<std::thread> pool;
-            for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
-            work();
-            for (std::thread &t : pool) t.join();
-          }));
-        }
-        ph.rows += ph.lap();
-        for (Work const &wk : batch_p) advance(wk.pair);
-        ph.windows += ph.lap();
-      }
-    }
-    // the decoders of this chunk's profiles go with the chunk (a memo of (K + 3) * 1364 bytes each; the formatter
-    // jobs hold their own references): a Pfam-sized database with hits on most profiles would pin gigabytes
-    for (int p = p0; p < p1; ++p) x->decoders[(size_t)p].reset();
-    x->done_proteins += p1 - p0;
   }
+  else
+  {
+    for (int p = 0; p < nprof; ++p)
+      for (int s = 0; s < nseq; ++s)
+        if (!batch->seqs[(size_t)s].nt.empty())
+          st.push_back(PairState{p, s, DcpWindow((int)batch->seqs[(size_t)s].nt.size(), dcp_hip_profile_core_size(x->eng, p)),
+                                 nullptr, nullptr});
+    for (size_t i = 0; i < st.size(); ++i) advance(i);
+  }
+  // the rounds of what is left: windows to score again (or, with nothing speculated, every window), their path passes
+  while ((!need_cost.empty() || !need_path.empty()) && !x->interrupted)
+  {
+    if (!need_cost.empty() && (rc = run_cost_batch())) return rc;
+    if (!need_path.empty() && (rc = run_path_batch())) return rc;
+  }
+  if (!speculate) x->done_proteins += nprof;
+  for (int p = 0; p < nprof; ++p) x->decoders[(size_t)p].reset();
 
   formatters.join();
   if (decode_rc) return raise(decode_rc, __func__); // c-core/match.c:66-89 fails the scan the same way
