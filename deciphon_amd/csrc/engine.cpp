@@ -790,6 +790,8 @@ struct dcp_hip *dcp_hip_new(int device)
   // wavefronts are bound by latency, not by issue slots, and slip in beside a cost pass in flight
   int prio_low = 0, prio_high = 0;
   ok = ok && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess;
+  if (char const *e = getenv("DECIPHON_HIP_PATH_STREAM_PRIORITY")) // experiment: 0 = the same priority as the cost streams
+    if (e[0] == '0') prio_high = 0;
   ok = ok && hipStreamCreateWithPriority(&x->path_set.stream, hipStreamNonBlocking, prio_high) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&x->path_set.fork_ev, hipEventDisableTiming) == hipSuccess;
   for (int c = 0; ok && c < DCP_NUM_CLASSES; ++c)

@@ -385,10 +385,11 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   // (c-core/window.c:21-31, c-core/thread.c:162) -- but hits are rare, and while a pair has had none its chain is the
   // same for every pair with that read length and core size.  So the profiles are scored SPECULATIVELY, chunk by
   // chunk: every window of every pair's no-hit chain in one batch (cost pass + LRT filter on the device,
-  // c-core/thread.c:114-121).  Two batches are kept in flight (dcp_hip_cost_hits_begin): while the GPU scores chunks
-  // c + 1 and c + 2 the host takes the hits of chunk c through the path pass (c-core/thread.c:123-166: viterbi_path,
-  // trellis_unzip, hit span, last_hit_pos; on streams of its own, beside the cost kernels) and formats their rows.
-  // Pairs without a hit are done.  A pair with hits walks its real chain: while the windows that follow a hit are
+  // c-core/thread.c:114-121).  Two batches are kept in flight (dcp_hip_cost_hits_begin): the host builds, sorts and
+  // uploads the window list of the next chunk while the GPU scores this one, and the kernels of a chunk follow those
+  // of the chunk before class by class, so the GPU never drains in between.  Pairs without a hit are done.  The
+  // hits go through the path pass (c-core/thread.c:123-166: viterbi_path, trellis_unzip, hit span, last_hit_pos) when
+  // the cost batches are through; a pair with hits then walks its real chain: while the windows that follow a hit are
   // still the speculated ones their scores stand, otherwise they are scored again -- in a few small rounds at the end.
   // Rows are emitted in the reference's order (profile, read, window) whatever the order of work.
   // DECIPHON_HIP_SPECULATE=0: nothing is assumed, every pair goes round by round (the tests compare the two).
@@ -407,9 +408,9 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     }
     return &it->second;
   };
-  // chunks of profiles: small enough for the window table of a chunk (2^21 pairs), and -- when the scan is large --
-  // about 1e11 DP cells each (~0.1 s of cost pass: a few times what a path pass takes, so that the two batches in
-  // flight outlast the host's work on the chunk before them)
+  // chunks of profiles: small enough for the window table of a chunk (2^21 pairs); the first one is kept short
+  // (~4e10 DP cells, a few dozen milliseconds of cost pass) so that the GPU starts early and the host builds and
+  // sorts the window list of the second chunk meanwhile.  DECIPHON_HIP_CHUNK_CELLS: cells per chunk (experiments).
   std::vector<std::pair<int, int>> chunks;
   {
     double read_nt = 0;
@@ -417,12 +418,13 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     size_t const max_pairs = 1u << 21;
     int const by_pairs = nseq > 0 ? (int)std::max<size_t>(1, max_pairs / (size_t)nseq) : std::max(nprof, 1);
     char const *cells_env = getenv("DECIPHON_HIP_CHUNK_CELLS");
-    double const chunk_cells = cells_env ? atof(cells_env) : 1.0e11;
+    double const chunk_cells = cells_env ? atof(cells_env) : 0.0;
     for (int p0 = 0; p0 < nprof;)
     {
       int p1 = p0;
       double cells = 0;
-      while (p1 < nprof && p1 - p0 < by_pairs && (p1 == p0 || cells < chunk_cells))
+      double const limit = chunk_cells > 0 ? chunk_cells : p0 == 0 ? 4.0e10 : 1.0e300;
+      while (p1 < nprof && p1 - p0 < by_pairs && (p1 == p0 || cells < limit))
         cells += read_nt * (double)dcp_hip_profile_core_size(x->eng, p1++);
       chunks.emplace_back(p0, p1);
       p0 = p1;
@@ -680,8 +682,11 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
       nwindows += f.wins.size() - speculated_of_hit_pairs; // the windows of the pairs without a hit are final
       for (size_t i = first_new; i < st.size(); ++i) advance(i);
       ph.windows += ph.lap();
-      // the path passes of this chunk's hits, beside the batches in flight; what needs scoring again waits for the end
-      while (!need_path.empty() && !x->interrupted)
+      // The path passes of the hits so far -- once no batch is in flight: beside a cost pass the path kernels, few
+      // wavefronts bound by memory latency, take several times as long and hold the cost kernels up for as long
+      // (whichever priority their streams have: profiles/r03_scan_pipeline.txt), so the scan gains nothing from the
+      // overlap and a short one loses.  What needs scoring again waits for the end as well.
+      while (flight.empty() && !need_path.empty() && !x->interrupted)
         if ((rc = run_path_batch())) return rc;
       // the decoders of this chunk's profiles go with the chunk once its rows are under way (a memo of (K + 3) * 1364
       // bytes each; the formatter jobs hold their own references): a Pfam-sized database with hits on most profiles
@@ -702,8 +707,8 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   // the rounds of what is left: windows to score again (or, with nothing speculated, every window), their path passes
   while ((!need_cost.empty() || !need_path.empty()) && !x->interrupted)
   {
-    if (!need_cost.empty() && (rc = run_cost_batch())) return rc;
     if (!need_path.empty() && (rc = run_path_batch())) return rc;
+    if (!need_cost.empty() && (rc = run_cost_batch())) return rc;
   }
   if (!speculate) x->done_proteins += nprof;
   for (int p = 0; p < nprof; ++p) x->decoders[(size_t)p].reset();

@@ -448,6 +448,9 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_path_blocks_kern
     w.ckpt_out = ckpt;
     w.ckpt_every = B;
     w.init(pool, pf, codes, xt);
+    // the path pass runs beside the cost kernels of the batches in flight (dcp_scan_run): its few wavefronts are bound
+    // by latency, so they go first wherever they share a SIMD -- what they take from the others is a few per cent
+    wave_priority<3>();
     w.run(pb.L, out + 2 * (size_t)pb.out);
   }
   int const slots = dcp_block_slots(pb.L, B);
@@ -462,6 +465,7 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_path_blocks_kern
       w.row_base = block * B;
       if (block > 0) w.ckpt_in = ckpt + (size_t)(block - 1) * (size_t)dcp_ckpt_floats(pf.Kp, W);
       w.init(pool, pf, codes, xt);
+      wave_priority<3>();
       int const last = B > 0 ? (block + 1) * B + 5 : pb.L;
       w.run(pb.L, out + 2 * (size_t)pb.out, last < pb.L ? last : pb.L);
     }
