@@ -1425,14 +1425,15 @@ int dcp_hip_run_staged(struct dcp_hip *x, int reps, float *ms, double *cells)
   HIP_TRY(x, hipEventCreate(&e0), DCP_EFUNCUSE);
   HIP_TRY(x, hipEventCreate(&e1), DCP_EFUNCUSE);
   HIP_TRY(x, hipEventRecord(e0, x->stream), DCP_EFUNCUSE);
-  // the passes as the batches of a scan follow each other (dcp_hip_cost_hits_begin while another batch is in flight):
-  // kernel class by kernel class, not pass by pass.  DECIPHON_HIP_STEP_JOIN=1: every pass joined before the next starts.
+  // every pass joined before the next starts.  DECIPHON_HIP_STEP_JOIN=0 (experiment): the passes follow each other as
+  // the batches of a scan do (dcp_hip_cost_hits_begin while another batch is in flight), kernel class by kernel class --
+  // measured no faster on the bench's 0.4 s steps (profiles/r03_scan_pipeline.txt)
   char const *join_env = getenv("DECIPHON_HIP_STEP_JOIN");
   int rc = 0;
-  if (join_env && join_env[0] == '1')
-    for (int i = 0; i < reps && !rc; ++i) rc = launch_cost_all(x, st);
-  else if (reps > 0)
+  if (join_env && join_env[0] == '0' && reps > 0)
     rc = launch_cost_all(x, st, nullptr, reps);
+  else
+    for (int i = 0; i < reps && !rc; ++i) rc = launch_cost_all(x, st);
   if (rc) return rc;
   HIP_TRY(x, hipEventRecord(e1, x->stream), DCP_EFUNCUSE);
   HIP_TRY(x, hipEventSynchronize(e1), DCP_EFUNCUSE);
