@@ -89,6 +89,12 @@ DCP_HDI int dcp_num_blocks(int L, int B) { return B <= 0 || L <= B + 5 ? 1 : (L 
 // rows a block's table holds, the row the block starts from included (row 0 for block 0)
 DCP_HDI int dcp_block_slots(int L, int B) { return (B <= 0 || L <= B + 5 ? L : B + 5) + 1; }
 
+// floats of one block's table: specials[slots][DCP_SP_STRIDE] + cells[slots][3][Kp]
+DCP_HDI long long dcp_block_table_floats(int L, int Kp, int B)
+{
+  return (long long)dcp_block_slots(L, B) * (DCP_SP_STRIDE + 3LL * Kp);
+}
+
 // where the traceback of one window stands between blocks (all zero = not started)
 struct DcpTraceState
 {

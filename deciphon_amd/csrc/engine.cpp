@@ -221,6 +221,7 @@ struct dcp_hip
   DevBuf<unsigned char> d_trellis; // trellises of the literal path pass
   std::vector<dcp_hip_window> path_wins; // the windows of the last dcp_hip_path
   int path_redone = 0;                   // how many of them needed the literal pass
+  int path_group = 1;                    // blocks of a window computed side by side in the fast path pass
   DevBuf<uint32_t> d_steps, d_compact;
   DevBuf<int64_t> d_step_off, d_compact_off;
   DevBuf<int32_t> d_nsteps;
@@ -316,7 +317,11 @@ int ckpt_rows()
 // one block's table, then the window's checkpoints (16-byte aligned)
 size_t block_table_bytes(int L, int Kp, int B) { return (size_t)dcp_block_slots(L, B) * (DCP_SP_STRIDE + 3 * (size_t)Kp) * 4; }
 size_t ckpt_bytes(int L, int Kp, int W, int B) { return (size_t)(dcp_num_blocks(L, B) - 1) * (size_t)dcp_ckpt_floats(Kp, W) * 4; }
-size_t fast_bytes(int L, int Kp, int W, int B) { return ((block_table_bytes(L, Kp, B) + 15) & ~(size_t)15) + ckpt_bytes(L, Kp, W, B); }
+// (G tables side by side when G blocks of a window are computed at once: dcp_cost_store_kernel)
+size_t fast_bytes(int L, int Kp, int W, int B, int G = 1)
+{
+  return (((size_t)std::min(G, dcp_num_blocks(L, B)) * block_table_bytes(L, Kp, B) + 15) & ~(size_t)15) + ckpt_bytes(L, Kp, W, B);
+}
 
 // v reordered by key(v[i]) in [0, nkeys), equal keys keeping their order: count, prefix, scatter
 template <class Key> void bucket_stable(std::vector<DcpProblem> &v, int nkeys, Key key)
@@ -1697,8 +1702,10 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
     HostProfile const &hp = x->profiles[(size_t)p.profile];
     if (hp.cls != DCP_STRIP_CLASS) // (the strip class keeps whole tables: dcp_hip_path placed table_bytes for it)
     {
-      ckpt_addr[(size_t)p.out] = p.trellis + (int64_t)((block_table_bytes(p.L, hp.Kp, B) + 15) & ~(size_t)15);
-      max_blocks = std::max(max_blocks, dcp_num_blocks(p.L, B));
+      int const nb = dcp_num_blocks(p.L, B);
+      ckpt_addr[(size_t)p.out] =
+          p.trellis + (int64_t)(((size_t)std::min(x->path_group, nb) * block_table_bytes(p.L, hp.Kp, B) + 15) & ~(size_t)15);
+      max_blocks = std::max(max_blocks, nb);
     }
   }
   HIP_TRY(x, x->d_ckpt_addr.reserve((size_t)n), DCP_ENOMEM);
@@ -1743,16 +1750,20 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
         HIP_TRY(x, dcp_launch_cost_store(c, a, nullptr, 0, 0), DCP_EFUNCUSE);
         HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, 0, 0), DCP_EFUNCUSE);
       }
-      else if (fused) // one launch: every window walks its own blocks (dcp_path_blocks_kernel)
+      else if (x->path_group <= 1 && fused) // one launch: every window walks its own blocks (dcp_path_blocks_kernel)
         HIP_TRY(x, dcp_launch_path_blocks(c, a, x->d_ckpt_addr.p, B, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p),
                 DCP_EFUNCUSE);
-      else // DECIPHON_HIP_PATH_FUSED=0: a launch per block and phase (tests compare the two)
+      else
       {
+        // The checkpoints; then, G blocks at a time from the last to the first, the rows of those blocks of every
+        // window -- a workgroup per (window, block): G times the wavefronts, each walking 1 / blocks of the rows --
+        // and the traceback through them.  (G = 1 with DECIPHON_HIP_PATH_FUSED=0: a launch per block and phase.)
+        int const G = std::max(x->path_group, 1);
         if (max_blocks > 1) HIP_TRY(x, dcp_launch_cost_ckpt(c, a, x->d_ckpt_addr.p, B), DCP_EFUNCUSE);
-        for (int block = max_blocks - 1; block >= 0; --block)
+        for (int it = 0; it * G < max_blocks; ++it)
         {
-          HIP_TRY(x, dcp_launch_cost_store(c, a, x->d_ckpt_addr.p, B, block), DCP_EFUNCUSE);
-          HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, B, block), DCP_EFUNCUSE);
+          HIP_TRY(x, dcp_launch_cost_store(c, a, x->d_ckpt_addr.p, B, 0, G, it), DCP_EFUNCUSE);
+          HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, B, 0, G, it), DCP_EFUNCUSE);
         }
       }
       if (fork)
@@ -1858,6 +1869,31 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
     size_t const budget = path_budget(x);
     int const B = ckpt_rows();
     dcp_hip_window const *ws = x->path_sorted.data();
+    // How many blocks of a window are computed side by side: as many as the budget holds tables for, for ALL the
+    // windows of the request at once -- with few hits every block of every window (the rows of a window are then
+    // walked once by one wavefront, for the checkpoints, and once by many); with many hits one (a slice of windows
+    // fills the GPU by itself).  DECIPHON_HIP_PATH_GROUP overrides.
+    {
+      double one = 0, fixed = 0;
+      int most = 1;
+      for (int i = 0; i < n; ++i)
+      {
+        HostProfile const &hp = x->profiles[(size_t)ws[i].profile];
+        int const L = ws[i].stop - ws[i].start;
+        if (hp.cls == DCP_STRIP_CLASS)
+          fixed += (double)table_bytes(L, hp.Kp);
+        else
+        {
+          one += (double)block_table_bytes(L, hp.Kp, B);
+          fixed += (double)ckpt_bytes(L, hp.Kp, hp.W, B);
+          most = std::max(most, dcp_num_blocks(L, B));
+        }
+      }
+      double const room = 0.9 * (double)budget - fixed;
+      int G = one > 0 && room > one ? (int)std::min<double>(room / one, (double)most) : 1;
+      if (char const *e = getenv("DECIPHON_HIP_PATH_GROUP")) G = std::max(atoi(e), 1);
+      x->path_group = std::max(1, std::min(G, most));
+    }
     for (int b = 0; b < n;)
     {
       int e = b;
@@ -1869,7 +1905,7 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
         HostProfile const &hp = x->profiles[(size_t)ws[e].profile];
         int const L = ws[e].stop - ws[e].start;
         unsigned char *at = x->tables.place(
-            hp.cls == DCP_STRIP_CLASS ? table_bytes(L, hp.Kp) : fast_bytes(L, hp.Kp, hp.W, B), budget);
+            hp.cls == DCP_STRIP_CLASS ? table_bytes(L, hp.Kp) : fast_bytes(L, hp.Kp, hp.W, B, x->path_group), budget);
         if (!at) break;
         x->table_addr.push_back((int64_t)(uintptr_t)at);
         ++e;

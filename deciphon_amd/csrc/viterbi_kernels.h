@@ -51,9 +51,12 @@ hipError_t dcp_launch_unzip(DcpLaunch const &a, uint32_t *steps, int64_t const *
 // traceback of every problem of a.problems (all classes) into steps / nsteps (as dcp_launch_unzip)
 // (in blocks, dcp_types.h: B rows between checkpoints, 0 = whole windows; ckpt_addr[out] = the window's checkpoints)
 hipError_t dcp_launch_cost_ckpt(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B);
-hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block);
+// G = 0: block `block` of every window.  G > 0: launch `it` of the groups of G blocks -- block nb - 1 - (it * G + g) of
+// every window, g = 0 .. G - 1, into table g of the window's G block tables (dcp_block_table_floats apart), one
+// workgroup per (window, g); the traceback then walks those blocks, the highest first
+hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block, int G = 0, int it = 0);
 hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps,
-                                DcpTraceState *states, int B, int block);
+                                DcpTraceState *states, int B, int block, int G = 0, int it = 0);
 // the same for every window of a.problems (one class, not the strip class) in ONE launch: a workgroup takes its window
 // through the checkpoints, then block by block through rows + traceback (DcpProblem::trellis = the table's address)
 hipError_t dcp_launch_path_blocks(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, uint32_t *steps,

@@ -93,6 +93,10 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_ckpt_kernel
 // recomputed from its checkpoint into the window's table -- float specials[slots][8] followed by float
 // cells[slots][3][Kp], slots = rows of a block + 1, row l at slot l - block * B.  B = 0: the whole window is one
 // block and the table holds all its rows (what the trellis replay of the strip class reads).
+// G > 0: G blocks of every window side by side, one workgroup each -- the blocks of a window are independent once its
+// checkpoints exist, and a lone wavefront per window leaves the GPU empty and waits out every row's latency by itself
+// (profiles/r03_scan_pipeline.txt).  Workgroup b takes window b / G and, in launch `it`, its block
+// nb - 1 - (it * G + b % G) (the last blocks first), into table b % G of the window's G tables.
 template <int Q, int W>
 __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_store_kernel(float const *__restrict__ pool,
                                                             DcpProfileDev const *__restrict__ profiles,
@@ -101,17 +105,28 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_store_kerne
                                                             float const *__restrict__ xt_table,
                                                             unsigned char *__restrict__ arena,
                                                             int64_t const *__restrict__ ckpt_addr, int B, int block,
-                                                            float *__restrict__ out, int nprob)
+                                                            int G, int it, float *__restrict__ out, int nprob)
 {
-  if ((int)blockIdx.x >= nprob) return;
-  int const p = dcp_xcd_remap((int)blockIdx.x, nprob);
+  int p, sub = 0;
+  if (G > 0)
+  {
+    if ((int)blockIdx.x >= nprob * G) return;
+    p = (int)blockIdx.x / G;
+    sub = (int)blockIdx.x % G;
+  }
+  else
+  {
+    if ((int)blockIdx.x >= nprob) return;
+    p = dcp_xcd_remap((int)blockIdx.x, nprob);
+  }
   DcpProblem const pb = problems[p];
-  if (block >= dcp_num_blocks(pb.L, B)) return;
+  if (G > 0) block = dcp_num_blocks(pb.L, B) - 1 - (it * G + sub);
+  if (block < 0 || block >= dcp_num_blocks(pb.L, B)) return;
   DcpProfileDev const pf = profiles[pb.profile];
   CostWave<Q, W, true> w;
   int const slots = dcp_block_slots(pb.L, B);
   // integer arithmetic: the engine passes arena = 0 and absolute table addresses in pb.trellis
-  w.tab_sp = dcp_global<float>((uintptr_t)arena + (uintptr_t)pb.trellis);
+  w.tab_sp = dcp_global<float>((uintptr_t)arena + (uintptr_t)pb.trellis) + (size_t)sub * dcp_block_table_floats(pb.L, pf.Kp, B);
   w.tab_cells = w.tab_sp + (size_t)slots * DCP_SP_STRIDE;
   w.row_base = block * B;
   if (block > 0)
@@ -392,12 +407,12 @@ __global__ __launch_bounds__(64) void dcp_traceback_kernel(
     float const *__restrict__ pool, DcpProfileDev const *__restrict__ profiles, DcpProblem const *__restrict__ problems,
     DcpCodeRow const *__restrict__ code_rows, float const *__restrict__ xt_table,
     unsigned char const *__restrict__ arena, uint32_t *__restrict__ steps, int64_t const *__restrict__ step_off,
-    int32_t *__restrict__ nsteps, DcpTraceState *__restrict__ states, int B, int block, int nprob)
+    int32_t *__restrict__ nsteps, DcpTraceState *__restrict__ states, int B, int block, int G, int it, int nprob)
 {
   int const p = (int)blockIdx.x;
   if (p >= nprob) return;
   DcpProblem const pb = problems[p];
-  if (block >= dcp_num_blocks(pb.L, B)) return;
+  int const nb = dcp_num_blocks(pb.L, B);
   DcpTraceState *st = states + pb.out;
   if (st->status != 0) return; // finished, or given up, in a later block
   DcpProfileDev const pf = profiles[pb.profile];
@@ -405,19 +420,30 @@ __global__ __launch_bounds__(64) void dcp_traceback_kernel(
   in.K = pf.K;
   in.Kp = pf.Kp;
   in.L = pb.L;
-  in.sp = dcp_global<float const>((uintptr_t)arena + (uintptr_t)pb.trellis);
-  in.cells = in.sp + (size_t)dcp_block_slots(pb.L, B) * DCP_SP_STRIDE;
   in.rows = pool + pf.rows_off;
   in.trans = pool + pf.trans_off;
   in.codes = code_rows + pb.code_row;
   in.xt = xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE;
-  in.row_base = block * B;
-  in.lo = block > 0 ? block * B + 5 : -1;
-  int const r = dcp_traceback_wave(in, steps + step_off[pb.out], step_off[pb.out + 1] - step_off[pb.out], st);
-  if ((threadIdx.x & 63) == 0 && r != 0)
+  float const *tables = dcp_global<float const>((uintptr_t)arena + (uintptr_t)pb.trellis);
+  // G > 0: through the (up to) G blocks launch `it` of dcp_cost_store_kernel has just written, the highest first
+  for (int sub = 0; sub < (G > 0 ? G : 1); ++sub)
   {
-    st->status = r > 0 ? 1 : r;
-    nsteps[pb.out] = r;
+    int const b = G > 0 ? nb - 1 - (it * G + sub) : block;
+    if (b < 0 || b >= nb) return;
+    in.sp = tables + (size_t)sub * dcp_block_table_floats(pb.L, pf.Kp, B);
+    in.cells = in.sp + (size_t)dcp_block_slots(pb.L, B) * DCP_SP_STRIDE;
+    in.row_base = b * B;
+    in.lo = b > 0 ? b * B + 5 : -1;
+    int const r = dcp_traceback_wave(in, steps + step_off[pb.out], step_off[pb.out + 1] - step_off[pb.out], st);
+    if (r != 0)
+    {
+      if ((threadIdx.x & 63) == 0)
+      {
+        st->status = r > 0 ? 1 : r;
+        nsteps[pb.out] = r;
+      }
+      return;
+    }
   }
 }
 
@@ -886,30 +912,32 @@ hipError_t dcp_launch_cost_narrow(int cls, DcpLaunch const &a)
   }
 }
 
-template <int Q, int W> static hipError_t launch_store_qw(DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block)
+template <int Q, int W>
+static hipError_t launch_store_qw(DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block, int G, int it)
 {
-  hipLaunchKernelGGL((dcp_cost_store_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool,
-                     a.profiles, a.problems, a.code_rows, a.xt_table, a.arena, ckpt_addr, B, block, a.out, a.nprob);
+  hipLaunchKernelGGL((dcp_cost_store_kernel<Q, W>), dim3((unsigned)a.nprob * (unsigned)(G > 0 ? G : 1)), dim3(64 * W), 0,
+                     a.stream, a.pool, a.profiles, a.problems, a.code_rows, a.xt_table, a.arena, ckpt_addr, B, block, G, it,
+                     a.out, a.nprob);
   return hipGetLastError();
 }
 
-hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block)
+hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block, int G, int it)
 {
   if (a.nprob <= 0) return hipSuccess;
   switch (cls)
   {
-  case 0: return launch_store_qw<1, 1>(a, ckpt_addr, B, block);
-  case 1: return launch_store_qw<2, 1>(a, ckpt_addr, B, block);
-  case 2: return launch_store_qw<3, 1>(a, ckpt_addr, B, block);
-  case 3: return launch_store_qw<4, 1>(a, ckpt_addr, B, block);
-  case 4: return launch_store_qw<6, 1>(a, ckpt_addr, B, block);
-  case 5: return launch_store_qw<8, 1>(a, ckpt_addr, B, block);
-  case 6: return launch_store_qw<6, 2>(a, ckpt_addr, B, block);
-  case 7: return launch_store_qw<4, 4>(a, ckpt_addr, B, block);
-  case 8: return launch_store_qw<6, 4>(a, ckpt_addr, B, block);
-  case 9: return launch_store_qw<8, 4>(a, ckpt_addr, B, block);
-  case 10: return launch_store_qw<8, 8>(a, ckpt_addr, B, block);
-  case DCP_STRIP_CLASS: return B == 0 && block == 0 ? launch_strip<true>(a) : hipErrorInvalidValue; // whole tables only
+  case 0: return launch_store_qw<1, 1>(a, ckpt_addr, B, block, G, it);
+  case 1: return launch_store_qw<2, 1>(a, ckpt_addr, B, block, G, it);
+  case 2: return launch_store_qw<3, 1>(a, ckpt_addr, B, block, G, it);
+  case 3: return launch_store_qw<4, 1>(a, ckpt_addr, B, block, G, it);
+  case 4: return launch_store_qw<6, 1>(a, ckpt_addr, B, block, G, it);
+  case 5: return launch_store_qw<8, 1>(a, ckpt_addr, B, block, G, it);
+  case 6: return launch_store_qw<6, 2>(a, ckpt_addr, B, block, G, it);
+  case 7: return launch_store_qw<4, 4>(a, ckpt_addr, B, block, G, it);
+  case 8: return launch_store_qw<6, 4>(a, ckpt_addr, B, block, G, it);
+  case 9: return launch_store_qw<8, 4>(a, ckpt_addr, B, block, G, it);
+  case 10: return launch_store_qw<8, 8>(a, ckpt_addr, B, block, G, it);
+  case DCP_STRIP_CLASS: return B == 0 && block == 0 && G == 0 ? launch_strip<true>(a) : hipErrorInvalidValue; // whole tables only
   default: return hipErrorInvalidValue;
   }
 }
@@ -972,11 +1000,11 @@ hipError_t dcp_launch_path_blocks(int cls, DcpLaunch const &a, int64_t const *ck
 }
 
 hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps,
-                                DcpTraceState *states, int B, int block)
+                                DcpTraceState *states, int B, int block, int G, int it)
 {
   if (a.nprob <= 0) return hipSuccess;
   hipLaunchKernelGGL(dcp_traceback_kernel, dim3((unsigned)a.nprob), dim3(64), 0, a.stream, a.pool, a.profiles, a.problems,
-                     a.code_rows, a.xt_table, a.arena, steps, step_off, nsteps, states, B, block, a.nprob);
+                     a.code_rows, a.xt_table, a.arena, steps, step_off, nsteps, states, B, block, G, it, a.nprob);
   return hipGetLastError();
 }
 

@@ -145,12 +145,16 @@ def test_lrt_filter_on_the_device(engine, orc):
     assert engine.cost_hits(wins[:0])[0].size == 0
 
 
+@pytest.mark.parametrize("mode", ["auto", "one launch per class", "three blocks side by side", "a launch per block"])
 @pytest.mark.parametrize("rows", ["50", "500", "0"])
-def test_fast_path_pass_in_blocks(engine, orc, monkeypatch, rows):
+def test_fast_path_pass_in_blocks(engine, orc, monkeypatch, rows, mode):
     """The fast path pass holds a window's DP table a block at a time (checkpoints of the folded ring every
     B rows, blocks recomputed from the last to the first, the traceback resumed from block to block): the
     same steps as the oracle's trellis_unzip with B = 50 (dozens of blocks), the default 500 and 0 (whole
-    tables), for every single-wave and multi-wave class, on windows with planted error-bearing domains."""
+    tables), for every single-wave and multi-wave class, on windows with planted error-bearing domains --
+    in each of the forms the engine chooses between by the HBM it has: as many blocks of a window side by side as the
+    table arena holds (auto: all of them here), one workgroup walking its window's blocks in one launch
+    (dcp_path_blocks_kernel), groups of three blocks, and a launch per block and phase."""
     import os
 
     from dcp_testlib import GOLDEN
@@ -158,6 +162,13 @@ def test_fast_path_pass_in_blocks(engine, orc, monkeypatch, rows):
     from oracle.dcp_reader import Protein
 
     monkeypatch.setenv("DECIPHON_HIP_CKPT_ROWS", rows)
+    if mode == "one launch per class":
+        monkeypatch.setenv("DECIPHON_HIP_PATH_GROUP", "1")
+    elif mode == "three blocks side by side":
+        monkeypatch.setenv("DECIPHON_HIP_PATH_GROUP", "3")
+    elif mode == "a launch per block":
+        monkeypatch.setenv("DECIPHON_HIP_PATH_GROUP", "1")
+        monkeypatch.setenv("DECIPHON_HIP_PATH_FUSED", "0")
     seeds = synth.load_seeds(os.path.join(GOLDEN, "minifam.dcp"))
     Ks = (40, 100, 173, 250, 300, 500, 700, 1000, 1500)
     prots = [synth.tile_protein(seeds, K, 11 * i, f"T{K}") for i, K in enumerate(Ks)]
