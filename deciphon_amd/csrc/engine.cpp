@@ -1290,8 +1290,11 @@ int dcp_hip_cost_hits_begin(struct dcp_hip *x, int n, struct dcp_hip_window cons
   Staged st;
   // the lists go up on a stream of their own and the kernels fork from there: a batch begun while another is in
   // flight is ordered behind it only kernel class by kernel class (the class streams), not as a whole
+  bool const timing = getenv("DECIPHON_HIP_TIMING") != nullptr && n > 1000;
+  auto const t0 = std::chrono::steady_clock::now();
   int rc = stage(x, n, w, ARENA_NONE, st, x->upload_stream);
   if (rc) return rc;
+  auto const t1 = std::chrono::steady_clock::now();
   if (n > 0)
   {
     HIP_TRY(x, B.d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
@@ -1309,6 +1312,12 @@ int dcp_hip_cost_hits_begin(struct dcp_hip *x, int n, struct dcp_hip_window cons
   B.up_groups.swap(st.pack_groups);
   B.n = n;
   x->outstanding[x->outstanding[0] >= 0 ? 1 : 0] = bank;
+  if (timing)
+  {
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "dcp_hip_cost_hits_begin: %d windows; stage %.1f ms, enqueue %.1f ms\n", n, ms(t0, t1),
+            ms(t1, std::chrono::steady_clock::now()));
+  }
   return 0;
 }
 
@@ -1322,7 +1331,11 @@ int dcp_hip_cost_hits_end(struct dcp_hip *x, int *nhits, int32_t *hit_window, fl
   *nhits = 0;
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   // whatever happens below, the batch is over once its device work is
+  auto const t0 = std::chrono::steady_clock::now();
   hipError_t const waited = n > 0 ? hipEventSynchronize(B.done_ev) : hipSuccess;
+  if (getenv("DECIPHON_HIP_TIMING") && n > 1000)
+    fprintf(stderr, "dcp_hip_cost_hits_end: %d windows; waited %.1f ms\n", n,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   B.n = -1;
   x->outstanding[0] = x->outstanding[1];
   x->outstanding[1] = -1;

@@ -84,7 +84,7 @@ class Scan:
 
     def __init__(self, dbfile, port: int = 0, num_threads: int = 1, multi_hits: bool = True,
                  hmmer3_compat: bool = False, cache: bool = False, partition=None, on_window=None,
-                 balanced: bool = False):
+                 balanced: bool = False, progress_callback: bool = True):
         self._lib = _lib()
         self._cscan = self._lib.dcp_scan_new()
         if not self._cscan:
@@ -100,7 +100,9 @@ class Scan:
                     self.interrupt()  # python-core/deciphon_core/scan.py:12-15
                     raise
 
-        self._cb = _CALLBACK(_cb)
+        # python-core always hands the library a callback (an empty function: it lets Python raise KeyboardInterrupt
+        # between windows); progress_callback=False hands it none, as a C caller may (c-core/test_scan.c:36-41)
+        self._cb = _CALLBACK(_cb) if progress_callback else C.cast(None, _CALLBACK)
         path = os.fsencode(getattr(dbfile, "path", dbfile))
         if partition is None:
             rc = self._lib.dcp_scan_setup(self._cscan, path, port, num_threads, multi_hits, hmmer3_compat, cache,

@@ -22,6 +22,7 @@ ap.add_argument("--profiles", type=int, default=400)
 ap.add_argument("--reads", type=int, default=500)
 ap.add_argument("--read-len", type=int, default=10000)
 ap.add_argument("--repeat", type=int, default=2)
+ap.add_argument("--no-callback", action="store_true", help="no progress callback (a C caller's NULL)")
 args = ap.parse_args()
 
 seeds = synth.load_seeds(bench.SEED_DB)
@@ -41,7 +42,7 @@ for i, r in enumerate(reads):
 wins = bench.all_windows(Ks, len(reads), args.read_len)
 cells = float((Ks[wins[:, 0]].astype(np.float64) * (wins[:, 3] - wins[:, 2])).sum())
 t2 = time.perf_counter()
-scan = Scan(dcp, 0, 1, True, False, False)
+scan = Scan(dcp, 0, 1, True, False, False, progress_callback=not args.no_callback)
 t3 = time.perf_counter()
 print(f"db: {args.profiles} profiles (sum K {int(Ks.sum())}), {os.path.getsize(dcp) / 1e6:.0f} MB written in {t1 - t0:.1f} s; "
       f"setup (ingest + H2D) {t3 - t2:.2f} s")
