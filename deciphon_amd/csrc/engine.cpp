@@ -60,6 +60,35 @@ template <class T> struct DevBuf
   }
 };
 
+// Pinned host memory for results that come back while other batches are in flight: a device-to-host copy into
+// PAGEABLE memory waits for everything the device has been given (measured: the 19 KB hit list of one batch took
+// 370 ms, the rest of the next batch's cost pass), a copy into pinned memory only for its own stream.
+template <class T> struct PinBuf
+{
+  T *p = nullptr;
+  size_t cap = 0;
+  ~PinBuf()
+  {
+    if (p) (void)hipHostFree(p);
+  }
+  hipError_t reserve(size_t n)
+  {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t const want = n + n / 4 + 1024;
+    hipError_t const e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess)
+    {
+      p = nullptr;
+      return e;
+    }
+    cap = want;
+    return hipSuccess;
+  }
+};
+
 // DP tables of the fast path pass: chunks that are allocated as slices need them and kept until
 // the engine goes (the driver wipes VRAM that is freed, and an allocation that lands on memory
 // still being wiped waits for it at ~30 GB/s -- scripts/alloc_timing.py; growing without ever
@@ -194,7 +223,7 @@ struct dcp_hip
     DevBuf<float> d_out;             // (null, alt) per window
     DevBuf<uint32_t> d_hits;         // dcp_hip_cost_hits: count, then (window, lrt bits) pairs
     DevBuf<float> d_ring;            // strip class (K > 4096): the rings of folded rows, one per workgroup in flight
-    uint32_t *hits_count = nullptr;  // the count on the host (pinned)
+    PinBuf<uint32_t> h_hits;         // ... on the host: the whole list comes back behind the filter
     hipEvent_t done_ev = nullptr;    // an outstanding batch: recorded behind its last device operation
     int n = -1;                      // windows of the outstanding batch, -1: none
     std::vector<DcpProblem> up_problems; // what the uploads of that batch read
@@ -204,7 +233,7 @@ struct dcp_hip
   Bank bank[3];
   int cur = 0;
   int outstanding[2] = {-1, -1}; // banks of the batches begun and not yet ended, oldest first
-  hipStream_t upload_stream = nullptr, fetch_stream = nullptr;
+  hipStream_t upload_stream = nullptr;
   // the path pass's own streams and events, swapped with stream / qstream / fork_ev / join_ev for its duration
   struct StreamSet
   {
@@ -222,6 +251,9 @@ struct dcp_hip
   std::vector<dcp_hip_window> path_wins; // the windows of the last dcp_hip_path
   int path_redone = 0;                   // how many of them needed the literal pass
   int path_group = 1;                    // blocks of a window computed side by side in the fast path pass
+  PinBuf<int32_t> h_nsteps;        // path pass results on the host (pinned: see PinBuf)
+  PinBuf<uint32_t> h_steps;
+  PinBuf<float> h_out;
   DevBuf<uint32_t> d_steps, d_compact;
   DevBuf<int64_t> d_step_off, d_compact_off;
   DevBuf<int32_t> d_nsteps;
@@ -805,11 +837,9 @@ struct dcp_hip *dcp_hip_new(int device)
     ok = ok && hipEventCreateWithFlags(&x->path_set.join_ev[c], hipEventDisableTiming) == hipSuccess;
   }
   ok = ok && hipStreamCreateWithFlags(&x->upload_stream, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&x->fetch_stream, hipStreamNonBlocking) == hipSuccess;
   for (int b = 0; ok && b < 2; ++b)
   {
     ok = ok && hipEventCreateWithFlags(&x->bank[b].done_ev, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&x->bank[b].hits_count, sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
   }
   if (!ok)
   {
@@ -836,11 +866,9 @@ void dcp_hip_del(struct dcp_hip *x)
   if (x->path_set.stream) (void)hipStreamDestroy(x->path_set.stream);
   if (x->path_set.fork_ev) (void)hipEventDestroy(x->path_set.fork_ev);
   if (x->upload_stream) (void)hipStreamDestroy(x->upload_stream);
-  if (x->fetch_stream) (void)hipStreamDestroy(x->fetch_stream);
   for (int b = 0; b < 3; ++b)
   {
     if (x->bank[b].done_ev) (void)hipEventDestroy(x->bank[b].done_ev);
-    if (x->bank[b].hits_count) (void)hipHostFree(x->bank[b].hits_count);
   }
   for (int c = 0; c < DCP_NUM_PACK_SHAPES; ++c)
   {
@@ -1299,10 +1327,13 @@ int dcp_hip_cost_hits_begin(struct dcp_hip *x, int n, struct dcp_hip_window cons
   {
     HIP_TRY(x, B.d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
     HIP_TRY(x, B.d_hits.reserve(1 + 2 * (size_t)n), DCP_ENOMEM);
+    HIP_TRY(x, B.h_hits.reserve(1 + 2 * (size_t)n), DCP_ENOMEM);
     HIP_TRY(x, hipMemsetAsync(B.d_hits.p, 0, sizeof(uint32_t), x->upload_stream), DCP_EFUNCUSE);
     if ((rc = launch_cost_all(x, st, x->upload_stream))) return rc;
     HIP_TRY(x, dcp_launch_lrt_filter(B.d_out.p, n, B.d_hits.p, x->stream), DCP_EFUNCUSE);
-    HIP_TRY(x, hipMemcpyAsync(B.hits_count, B.d_hits.p, sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream), DCP_EFUNCUSE);
+    // count and list together (8 B per window at most: nothing beside the kernels), into pinned memory
+    HIP_TRY(x, hipMemcpyAsync(B.h_hits.p, B.d_hits.p, (1 + 2 * (size_t)n) * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream),
+            DCP_EFUNCUSE);
     HIP_TRY(x, hipEventRecord(B.done_ev, x->stream), DCP_EFUNCUSE);
   }
   // `st` goes, but the vectors its uploads may still be reading live on in the bank until the batch is ended
@@ -1333,22 +1364,19 @@ int dcp_hip_cost_hits_end(struct dcp_hip *x, int *nhits, int32_t *hit_window, fl
   // whatever happens below, the batch is over once its device work is
   auto const t0 = std::chrono::steady_clock::now();
   hipError_t const waited = n > 0 ? hipEventSynchronize(B.done_ev) : hipSuccess;
-  if (getenv("DECIPHON_HIP_TIMING") && n > 1000)
-    fprintf(stderr, "dcp_hip_cost_hits_end: %d windows; waited %.1f ms\n", n,
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  auto const t1 = std::chrono::steady_clock::now();
   B.n = -1;
   x->outstanding[0] = x->outstanding[1];
   x->outstanding[1] = -1;
   if (waited != hipSuccess) return fail(x, DCP_EFUNCUSE, "hipEventSynchronize", waited);
   if (n == 0) return 0;
   if (!hit_window || !hit_lrt) return DCP_EFUNCUSE;
-  uint32_t const count = *B.hits_count;
+  uint32_t const count = B.h_hits.p[0];
+  if (getenv("DECIPHON_HIP_TIMING") && n > 1000)
+    fprintf(stderr, "dcp_hip_cost_hits_end: %d windows, %u hits; waited %.1f ms\n", n, count,
+            std::chrono::duration<double, std::milli>(t1 - t0).count());
   if (count == 0) return 0;
-  std::vector<uint32_t> pairs(2 * (size_t)count);
-  // (not on x->stream: a later batch may have work queued there)
-  HIP_TRY(x, hipMemcpyAsync(pairs.data(), B.d_hits.p + 1, pairs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, x->fetch_stream),
-          DCP_EFUNCUSE);
-  HIP_TRY(x, hipStreamSynchronize(x->fetch_stream), DCP_EFUNCUSE);
+  uint32_t const *pairs = B.h_hits.p + 1;
   std::vector<std::pair<uint32_t, uint32_t>> hits(count);
   for (uint32_t i = 0; i < count; ++i) hits[i] = {pairs[2 * (size_t)i], pairs[2 * (size_t)i + 1]};
   std::sort(hits.begin(), hits.end()); // the device appends in no particular order
@@ -1502,28 +1530,32 @@ std::vector<int64_t> step_offsets(dcp_hip *x, Staged const &st, int n)
 
 // Brings the step counts and then only the steps actually written to the host:
 // steps[compact[i] .. compact[i+1]) are window i's (empty where nsteps[i] < 0).
-int fetch_steps(dcp_hip *x, int n, std::vector<int32_t> &nsteps, std::vector<int64_t> &compact,
-                std::vector<uint32_t> &steps)
+int fetch_steps(dcp_hip *x, int n, int32_t const *&nsteps, std::vector<int64_t> &compact, uint32_t const *&steps,
+                size_t &total_steps)
 {
-  nsteps.resize((size_t)n);
-  HIP_TRY(x, hipMemcpyAsync(nsteps.data(), x->d_nsteps.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, x->stream),
+  HIP_TRY(x, x->h_nsteps.reserve((size_t)std::max(n, 1)), DCP_ENOMEM);
+  HIP_TRY(x, hipMemcpyAsync(x->h_nsteps.p, x->d_nsteps.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  nsteps = x->h_nsteps.p;
   compact.assign((size_t)n + 1, 0);
-  for (int i = 0; i < n; ++i) compact[(size_t)i + 1] = compact[(size_t)i] + (nsteps[(size_t)i] > 0 ? nsteps[(size_t)i] : 0);
+  for (int i = 0; i < n; ++i) compact[(size_t)i + 1] = compact[(size_t)i] + (nsteps[i] > 0 ? nsteps[i] : 0);
   size_t const total = (size_t)compact[(size_t)n];
-  steps.resize(total);
+  total_steps = total;
+  steps = nullptr;
   if (!total) return 0;
   HIP_TRY(x, x->d_compact_off.reserve((size_t)n + 1), DCP_ENOMEM);
   HIP_TRY(x, x->d_compact.reserve(total), DCP_ENOMEM);
+  HIP_TRY(x, x->h_steps.reserve(total), DCP_ENOMEM);
   HIP_TRY(x, hipMemcpyAsync(x->d_compact_off.p, compact.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
                             x->stream),
           DCP_EFUNCUSE);
   HIP_TRY(x, dcp_launch_compact_steps(x->d_steps.p, x->d_step_off.p, x->d_compact_off.p, x->d_compact.p, n, x->stream),
           DCP_EFUNCUSE);
-  HIP_TRY(x, hipMemcpyAsync(steps.data(), x->d_compact.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream),
+  HIP_TRY(x, hipMemcpyAsync(x->h_steps.p, x->d_compact.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
+  steps = x->h_steps.p;
   return 0;
 }
 
@@ -1634,13 +1666,15 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
     a.nprob = n;
     HIP_TRY(x, dcp_launch_unzip(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p), DCP_EFUNCUSE);
   }
-  std::vector<float> out((size_t)n);
-  std::vector<int32_t> nsteps;
+  HIP_TRY(x, x->h_out.reserve((size_t)n), DCP_ENOMEM);
+  float const *out = x->h_out.p;
+  int32_t const *nsteps = nullptr;
   std::vector<int64_t> compact;
-  std::vector<uint32_t> steps;
-  HIP_TRY(x, hipMemcpyAsync(out.data(), BK(x).d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+  uint32_t const *steps = nullptr;
+  size_t total_fetched = 0;
+  HIP_TRY(x, hipMemcpyAsync(x->h_out.p, BK(x).d_out.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
-  if ((rc = fetch_steps(x, n, nsteps, compact, steps))) return rc;
+  if ((rc = fetch_steps(x, n, nsteps, compact, steps, total_fetched))) return rc;
   // every earlier trellis offset pointed into the arena that was just rewritten
   for (PathResult &r : x->paths) r.has_trellis = r.trellis_on_host = false;
   for (DcpProblem const &p : st.problems)
@@ -1660,7 +1694,7 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
     // a trellis (process_window stops at a non-finite lrt, c-core/thread.c:118-121)
     if (!(r.score < INFINITY)) continue;
     if (ns >= 0)
-      unpack_steps(steps.data() + compact[(size_t)p.out], ns, r);
+      unpack_steps(steps + compact[(size_t)p.out], ns, r);
     else
     {
       // the device buffer was too small for this path: fetch the trellis and unzip here
@@ -1788,13 +1822,15 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
     for (hipEvent_t ev : joins) HIP_TRY(x, hipStreamWaitEvent(x->stream, ev, 0), DCP_EFUNCUSE);
   }
   tm.lap("traceback");
-  std::vector<float> out(2 * (size_t)n);
-  std::vector<int32_t> nsteps;
+  HIP_TRY(x, x->h_out.reserve(2 * (size_t)n), DCP_ENOMEM);
+  float const *out = x->h_out.p;
+  int32_t const *nsteps = nullptr;
   std::vector<int64_t> compact;
-  std::vector<uint32_t> steps;
-  HIP_TRY(x, hipMemcpyAsync(out.data(), BK(x).d_out.p, out.size() * sizeof(float), hipMemcpyDeviceToHost, x->stream),
+  uint32_t const *steps = nullptr;
+  size_t total_fetched = 0;
+  HIP_TRY(x, hipMemcpyAsync(x->h_out.p, BK(x).d_out.p, 2 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
-  if ((rc = fetch_steps(x, n, nsteps, compact, steps))) return rc;
+  if ((rc = fetch_steps(x, n, nsteps, compact, steps, total_fetched))) return rc;
   tm.lap("fetch");
   for (DcpProblem const &p : st.problems)
   {
@@ -1805,14 +1841,14 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
     r.has_trellis = r.trellis_on_host = false;
     int32_t const ns = nsteps[(size_t)p.out];
     if (ns >= 0)
-      unpack_steps(steps.data() + compact[(size_t)p.out], ns, r);
+      unpack_steps(steps + compact[(size_t)p.out], ns, r);
     else
       redo.push_back(x->path_order[(size_t)(b + p.out)]);
   }
   tm.lap("unpack");
   if (tm.on)
     fprintf(stderr, "dcp_hip_path: %d windows, tables %.2f GB of %.2f GB held (hipMalloc %.1f ms), %zu steps, %zu to redo;%s\n",
-            n, (double)x->tables.placed / 1e9, (double)x->tables.held / 1e9, x->tables.alloc_ms, steps.size(),
+            n, (double)x->tables.placed / 1e9, (double)x->tables.held / 1e9, x->tables.alloc_ms, total_fetched,
             redo.size(), tm.line.c_str());
   return 0;
 }

@@ -395,6 +395,8 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   // DECIPHON_HIP_SPECULATE=0: nothing is assumed, every pair goes round by round (the tests compare the two).
   char const *spec_env = getenv("DECIPHON_HIP_SPECULATE");
   bool const speculate = !(spec_env && spec_env[0] == '0');
+  char const *beside_env = getenv("DECIPHON_HIP_PATH_BESIDE"); // experiment: path passes beside the cost batches in flight
+  bool const path_beside = beside_env && beside_env[0] == '1';
   typedef std::vector<std::pair<int, int>> Chain; // [start, stop) of the windows of a pair that never hits
   std::map<std::pair<int, int>, Chain> chains;    // by (read length, core size)
   auto chain_of = [&](int seq_size, int core_size) -> Chain const * {
@@ -686,7 +688,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
       // wavefronts bound by memory latency, take several times as long and hold the cost kernels up for as long
       // (whichever priority their streams have: profiles/r03_scan_pipeline.txt), so the scan gains nothing from the
       // overlap and a short one loses.  What needs scoring again waits for the end as well.
-      while (flight.empty() && !need_path.empty() && !x->interrupted)
+      while ((flight.empty() || path_beside) && !need_path.empty() && !x->interrupted)
         if ((rc = run_path_batch())) return rc;
       // the decoders of this chunk's profiles go with the chunk once its rows are under way (a memo of (K + 3) * 1364
       // bytes each; the formatter jobs hold their own references): a Pfam-sized database with hits on most profiles

@@ -71,6 +71,8 @@ def load_library() -> C.CDLL:
     L.dcp_hip_xtrans.restype = None
     L.dcp_hip_cost.argtypes = [vp, i32, vp, vp, vp]
     L.dcp_hip_cost_hits.argtypes = [vp, i32, vp, C.POINTER(i32), vp, vp]
+    L.dcp_hip_cost_hits_begin.argtypes = [vp, i32, vp]
+    L.dcp_hip_cost_hits_end.argtypes = [vp, C.POINTER(i32), vp, vp]
     L.dcp_hip_cost_bench.argtypes = [vp, i32, vp, i32, i32, f32p, C.POINTER(C.c_double), vp, vp]
     L.dcp_hip_stage.argtypes = [vp, i32, vp]
     L.dcp_hip_run_staged.argtypes = [vp, i32, f32p, C.POINTER(C.c_double)]
@@ -252,6 +254,21 @@ class Engine:
         lrt = np.zeros(max(n, 1), dtype=np.float32)
         nh = C.c_int(0)
         self._check(self.lib.dcp_hip_cost_hits(self.h, n, arr, C.byref(nh), _p(idx), _p(lrt)))
+        return idx[: nh.value].copy(), lrt[: nh.value].copy()
+
+    def cost_hits_begin(self, windows) -> None:
+        """The first half of cost_hits: stages the windows, enqueues the kernels and returns while the GPU works.  Up to
+        two batches may be outstanding; cost_hits_end() delivers the oldest."""
+        n, arr = self._windows(windows)
+        self._check(self.lib.dcp_hip_cost_hits_begin(self.h, n, arr))
+        self._pending = getattr(self, "_pending", []) + [n]
+
+    def cost_hits_end(self):
+        n = self._pending.pop(0) if getattr(self, "_pending", None) else 0
+        idx = np.zeros(max(n, 1), dtype=np.int32)
+        lrt = np.zeros(max(n, 1), dtype=np.float32)
+        nh = C.c_int(0)
+        self._check(self.lib.dcp_hip_cost_hits_end(self.h, C.byref(nh), _p(idx), _p(lrt)))
         return idx[: nh.value].copy(), lrt[: nh.value].copy()
 
     def cost_bench(self, windows, warmup: int, reps: int):

@@ -200,3 +200,53 @@ def test_fast_path_pass_in_blocks(engine, orc, monkeypatch, rows, mode):
         ids, sizes = orc.unzip(prof.K, len(seq), xo, no)
         assert bits(r["score"]) == bits(score), (rows, p["core_size"], a, b)
         assert np.array_equal(r["state_ids"], ids) and np.array_equal(r["seqsizes"], sizes), (rows, p["core_size"], a, b)
+
+
+def test_two_cost_batches_in_flight_and_a_path_pass_between(orc):
+    """dcp_hip_cost_hits_begin / _end: two batches outstanding at once (the second queued behind the first on the same
+    kernel streams, its window lists in buffers of its own), a path pass between a _begin and its _end (it has buffers
+    and streams of its own too), every other call refused meanwhile -- and the hits of each batch equal to those of the
+    one-call form.  On a FRESH engine and process state: the first use of every buffer set."""
+    import time
+
+    import deciphon_amd
+    from dcp_testlib import random_seq, synth_profile
+
+    rng = np.random.default_rng(99)
+    profs = [synth_profile(rng, K, None, 0.02) for K in (12, 60, 173, 300, 640)]
+    reads = [random_seq(rng, 1500) for _ in range(400)]
+    for r in reads[::7]:  # domains that hit: the consensus-free way -- copy a stretch the model likes
+        r[100:400] = reads[0][100:400]
+    with deciphon_amd.Engine(0) as eng:
+        for p in profs:
+            eng.add_profile(p.K, p.trans, p.match, p.null, p.bg)
+        eng.commit()
+        eng.set_sequences(reads)
+        eng.set_mode(True, False)
+        small = np.array([(p, s, 0, 1500) for p in range(2) for s in range(40)], np.int32)
+        big = np.array([(p, s, a, a + 1200) for p in range(5) for s in range(400) for a in (0, 150, 300)], np.int32)
+        eng.cost_hits_begin(small)
+        eng.cost_hits_begin(big)  # while the first is in flight
+        with pytest.raises(deciphon_amd.HipError) as e:
+            eng.cost_hits_begin(small)  # a third: refused
+        assert e.value.code == 8
+        with pytest.raises(deciphon_amd.HipError):
+            eng.set_sequences(reads)  # anything that would pull the data from under the kernels: refused
+        paths = eng.path([tuple(int(v) for v in small[3])], trellis=False)  # allowed: its own buffers and streams
+        t0 = time.perf_counter()
+        got_small = eng.cost_hits_end()
+        got_big = eng.cost_hits_end()
+        waited = time.perf_counter() - t0
+        with pytest.raises(deciphon_amd.HipError):
+            eng.cost_hits_end()  # nothing outstanding
+        want_small, want_big = eng.cost_hits(small), eng.cost_hits(big)
+        for got, want in ((got_small, want_small), (got_big, want_big)):
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+        nul, alt = eng.cost(big)
+        lrt = (-2.0 * ((-nul) - (-alt))).astype(np.float32)
+        keep = np.nonzero(np.isfinite(lrt) & (lrt >= 0))[0]
+        assert np.array_equal(got_big[0], keep.astype(np.int32)) and len(keep) > 0
+        xt = orc.xtrans(1500 // 3, True, False)
+        p, s = int(small[3][0]), int(small[3][1])
+        assert bits(paths[0]["score"]) == bits(orc.cost(profs[p], xt, reads[s]))
+        print(f"two batches ({len(small)} + {len(big)} windows): ends waited {waited * 1e3:.1f} ms")
