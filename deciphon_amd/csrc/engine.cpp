@@ -332,6 +332,14 @@ struct Staged
   }
 };
 
+// for functions that enqueue copies from vectors of their own: whichever way they leave, the stream has passed the
+// copies before the vectors go (a no-op when the function has synchronised already)
+struct StreamDrain
+{
+  hipStream_t s;
+  ~StreamDrain() { (void)hipStreamSynchronize(s); }
+};
+
 enum ArenaKind { ARENA_NONE, ARENA_TRELLIS, ARENA_TABLE };
 
 // DP table of one window: float specials[(L+1)][8], float cells[(L+1)][3][Kp] (traceback.h)
@@ -1742,7 +1750,8 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
   HIP_TRY(x, BK(x).d_out.reserve(2 * (size_t)n), DCP_ENOMEM);
   int const B = ckpt_rows();
   // checkpoints sit behind each window's block table (dcp_hip_path placed fast_bytes per window)
-  std::vector<int64_t> ckpt_addr((size_t)n, 0);
+  std::vector<int64_t> ckpt_addr((size_t)n, 0), step_off;
+  StreamDrain drain{x->stream}; // destroyed before the two: an early return does not pull them from under a copy
   int max_blocks = 1;
   for (DcpProblem const &p : st.problems)
   {
@@ -1760,7 +1769,7 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
           DCP_EFUNCUSE);
   HIP_TRY(x, x->d_trace.reserve((size_t)n), DCP_ENOMEM);
   HIP_TRY(x, hipMemsetAsync(x->d_trace.p, 0, (size_t)n * sizeof(DcpTraceState), x->stream), DCP_EFUNCUSE);
-  std::vector<int64_t> step_off = step_offsets(x, st, n);
+  step_off = step_offsets(x, st, n);
   size_t const total_steps = (size_t)step_off[(size_t)n];
   HIP_TRY(x, x->d_steps.reserve(total_steps), DCP_ENOMEM);
   HIP_TRY(x, x->d_step_off.reserve((size_t)n + 1), DCP_ENOMEM);
