@@ -482,6 +482,40 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     std::vector<dcp_hip_window> hits(batch_p.size());
     for (size_t k = 0; k < batch_p.size(); ++k) hits[k] = batch_p[k].w;
     nhits += hits.size();
+    {
+      // decoder_setup (c-core/decoder.c:21-36) for the profiles of this batch -- reading a profile's distributions out
+      // of the database and exponentiating them -- by host threads WHILE the GPU walks the paths (this thread only
+      // waits for it meanwhile); the row formatters below find them ready
+      auto warm = std::make_shared<std::vector<std::pair<int, std::shared_ptr<dcp_scan::LazyDecoder>>>>();
+      for (Work const &wk : batch_p)
+      {
+        std::shared_ptr<dcp_scan::LazyDecoder> &d = x->decoders[(size_t)wk.w.profile];
+        if (d) continue;
+        d = std::make_shared<dcp_scan::LazyDecoder>();
+        warm->emplace_back(wk.w.profile, d);
+      }
+      if (!warm->empty())
+      {
+        dcp_scan const *scan = x;
+        formatters.add(std::thread([warm, scan]() {
+          std::atomic<size_t> next{0};
+          auto work = [&]() {
+            for (size_t k = next.fetch_add(1); k < warm->size(); k = next.fetch_add(1))
+            {
+              dcp_scan::LazyDecoder &ld = *(*warm)[k].second;
+              int const profile = (*warm)[k].first;
+              std::call_once(ld.once, [&]() { ld.rc = scan->db->read_decoder(scan->index_offset + profile, ld.dec); });
+            }
+          };
+          unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,
+                                                        (unsigned)std::max<size_t>(warm->size() / 4, 1)});
+          std::vector<std::thread> pool;
+          for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+          work();
+          for (std::thread &t : pool) t.join();
+        }));
+      }
+    }
     ph.windows += ph.lap();
     int prc = dcp_hip_path(x->eng, (int)hits.size(), hits.data());
     if (prc) return raise(prc, __func__, dcp_hip_strerror(x->eng));
