@@ -1791,37 +1791,7 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
     bool const fused = !(fused_env && fused_env[0] == '0');
     if (fork) HIP_TRY(x, hipEventRecord(x->fork_ev, x->stream), DCP_EFUNCUSE);
     std::vector<hipEvent_t> joins;
-    // groups of blocks: the single-wave classes (0..5, neighbours in the problem list) go out together -- the hardware
-    // runs four kernels side by side, and six class kernels on four queues took twice as long as the slowest of them
-    int sw_classes = 0;
-    for (int c = 0; c < 6; ++c) sw_classes += st.c_begin[c + 1] > st.c_begin[c];
-    bool const fuse_sw = fused && x->path_group > 1 && sw_classes >= 2;
-    if (fuse_sw)
-    {
-      DcpLaunch a = launch_args(x, st, 0);
-      a.nprob = st.c_begin[6] - st.c_begin[0];
-      a.arena = nullptr;
-      if (fork)
-      {
-        a.stream = x->qstream[0];
-        HIP_TRY(x, hipStreamWaitEvent(a.stream, x->fork_ev, 0), DCP_EFUNCUSE);
-      }
-      int const G = x->path_group;
-      int sw_blocks = 1;
-      for (int i = st.c_begin[0]; i < st.c_begin[6]; ++i) sw_blocks = std::max(sw_blocks, dcp_num_blocks(st.problems[(size_t)i].L, B));
-      if (sw_blocks > 1) HIP_TRY(x, dcp_launch_cost_ckpt_fused(a, x->d_ckpt_addr.p, B), DCP_EFUNCUSE);
-      for (int it = 0; it * G < sw_blocks; ++it)
-      {
-        HIP_TRY(x, dcp_launch_cost_store_fused(a, x->d_ckpt_addr.p, B, G, it), DCP_EFUNCUSE);
-        HIP_TRY(x, dcp_launch_traceback(a, x->d_steps.p, x->d_step_off.p, x->d_nsteps.p, x->d_trace.p, B, 0, G, it), DCP_EFUNCUSE);
-      }
-      if (fork)
-      {
-        HIP_TRY(x, hipEventRecord(x->join_ev[0], a.stream), DCP_EFUNCUSE);
-        joins.push_back(x->join_ev[0]);
-      }
-    }
-    for (int c = fuse_sw ? 6 : 0; c < DCP_NUM_CLASSES; ++c)
+    for (int c = 0; c < DCP_NUM_CLASSES; ++c)
     {
       DcpLaunch a = launch_args(x, st, c);
       if (a.nprob <= 0) continue;

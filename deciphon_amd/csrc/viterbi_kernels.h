@@ -57,10 +57,6 @@ hipError_t dcp_launch_cost_ckpt(int cls, DcpLaunch const &a, int64_t const *ckpt
 hipError_t dcp_launch_cost_store(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, int block, int G = 0, int it = 0);
 hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps,
                                 DcpTraceState *states, int B, int block, int G = 0, int it = 0);
-// checkpoints / groups of blocks of the windows of EVERY single-wave class (classes 0..5: a.problems may mix them) in one
-// launch each
-hipError_t dcp_launch_cost_ckpt_fused(DcpLaunch const &a, int64_t const *ckpt_addr, int B);
-hipError_t dcp_launch_cost_store_fused(DcpLaunch const &a, int64_t const *ckpt_addr, int B, int G, int it);
 // the same for every window of a.problems (one class, not the strip class) in ONE launch: a workgroup takes its window
 // through the checkpoints, then block by block through rows + traceback (DcpProblem::trellis = the table's address)
 hipError_t dcp_launch_path_blocks(int cls, DcpLaunch const &a, int64_t const *ckpt_addr, int B, uint32_t *steps,

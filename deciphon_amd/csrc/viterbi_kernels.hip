@@ -70,18 +70,6 @@ __global__ __launch_bounds__(64 * W, DCP_COST_WAVES(Q, W)) void dcp_cost_kernel(
 // Fast path pass in blocks (dcp_types.h).  First the checkpoints: the cost pass once more over the hit windows,
 // leaving the folded ring of five rows every B rows (windows of a single block need none and leave at once).
 template <int Q, int W>
-__device__ __forceinline__ void dcp_ckpt_body(float const *__restrict__ pool, DcpProfileDev const &pf, DcpProblem const &pb,
-                                              DcpCodeRow const *__restrict__ code_rows, float const *__restrict__ xt_table,
-                                              int64_t const *__restrict__ ckpt_addr, int B, float *__restrict__ out)
-{
-  CostWave<Q, W> w;
-  w.ckpt_out = dcp_global<float>((uintptr_t)ckpt_addr[pb.out]);
-  w.ckpt_every = B;
-  w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
-  w.run(pb.L, out + 2 * (size_t)pb.out);
-}
-
-template <int Q, int W>
 __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_ckpt_kernel(float const *__restrict__ pool,
                                                            DcpProfileDev const *__restrict__ profiles,
                                                            DcpProblem const *__restrict__ problems,
@@ -93,34 +81,12 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_ckpt_kernel
   if ((int)blockIdx.x >= nprob) return;
   DcpProblem const pb = problems[dcp_xcd_remap((int)blockIdx.x, nprob)];
   if (dcp_num_blocks(pb.L, B) <= 1) return;
-  dcp_ckpt_body<Q, W>(pool, profiles[pb.profile], pb, code_rows, xt_table, ckpt_addr, B, out);
-}
-
-// Every single-wave class (1, 2, 3, 4, 6, 8 positions per lane) in ONE launch: the path pass of a scan has a few
-// hundred windows per class, the hardware runs four kernels side by side whatever the number of streams, and six class
-// kernels queued on four queues took twice as long as the slowest of them (profiles/r03_scan_pipeline.txt).  The
-// register budget of the largest class costs nothing here: these windows are too few to fill the SIMDs.
-__global__ __launch_bounds__(64, 2) void dcp_cost_ckpt_fused_kernel(float const *__restrict__ pool,
-                                                                   DcpProfileDev const *__restrict__ profiles,
-                                                                   DcpProblem const *__restrict__ problems,
-                                                                   DcpCodeRow const *__restrict__ code_rows,
-                                                                   float const *__restrict__ xt_table,
-                                                                   int64_t const *__restrict__ ckpt_addr, int B,
-                                                                   float *__restrict__ out, int nprob)
-{
-  if ((int)blockIdx.x >= nprob) return;
-  DcpProblem const pb = problems[blockIdx.x];
-  if (dcp_num_blocks(pb.L, B) <= 1) return;
   DcpProfileDev const pf = profiles[pb.profile];
-  switch (pf.Q)
-  {
-  case 1: dcp_ckpt_body<1, 1>(pool, pf, pb, code_rows, xt_table, ckpt_addr, B, out); break;
-  case 2: dcp_ckpt_body<2, 1>(pool, pf, pb, code_rows, xt_table, ckpt_addr, B, out); break;
-  case 3: dcp_ckpt_body<3, 1>(pool, pf, pb, code_rows, xt_table, ckpt_addr, B, out); break;
-  case 4: dcp_ckpt_body<4, 1>(pool, pf, pb, code_rows, xt_table, ckpt_addr, B, out); break;
-  case 6: dcp_ckpt_body<6, 1>(pool, pf, pb, code_rows, xt_table, ckpt_addr, B, out); break;
-  default: dcp_ckpt_body<8, 1>(pool, pf, pb, code_rows, xt_table, ckpt_addr, B, out); break;
-  }
+  CostWave<Q, W> w;
+  w.ckpt_out = dcp_global<float>((uintptr_t)ckpt_addr[pb.out]);
+  w.ckpt_every = B;
+  w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
+  w.run(pb.L, out + 2 * (size_t)pb.out);
 }
 
 // Then, block by block from the last to the first: the rows of block `block` of every window that has one,
@@ -131,25 +97,6 @@ __global__ __launch_bounds__(64, 2) void dcp_cost_ckpt_fused_kernel(float const 
 // checkpoints exist, and a lone wavefront per window leaves the GPU empty and waits out every row's latency by itself
 // (profiles/r03_scan_pipeline.txt).  Workgroup b takes window b / G and, in launch `it`, its block
 // nb - 1 - (it * G + b % G) (the last blocks first), into table b % G of the window's G tables.
-template <int Q, int W>
-__device__ __forceinline__ void dcp_store_body(float const *__restrict__ pool, DcpProfileDev const &pf, DcpProblem const &pb,
-                                               DcpCodeRow const *__restrict__ code_rows, float const *__restrict__ xt_table,
-                                               unsigned char *__restrict__ arena, int64_t const *__restrict__ ckpt_addr, int B,
-                                               int block, int sub, float *__restrict__ out)
-{
-  CostWave<Q, W, true> w;
-  int const slots = dcp_block_slots(pb.L, B);
-  // integer arithmetic: the engine passes arena = 0 and absolute table addresses in pb.trellis
-  w.tab_sp = dcp_global<float>((uintptr_t)arena + (uintptr_t)pb.trellis) + (size_t)sub * dcp_block_table_floats(pb.L, pf.Kp, B);
-  w.tab_cells = w.tab_sp + (size_t)slots * DCP_SP_STRIDE;
-  w.row_base = block * B;
-  if (block > 0)
-    w.ckpt_in = dcp_global<float const>((uintptr_t)ckpt_addr[pb.out]) + (size_t)(block - 1) * (size_t)dcp_ckpt_floats(pf.Kp, W);
-  w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
-  int const last = B > 0 ? (block + 1) * B + 5 : pb.L;
-  w.run(pb.L, out + 2 * (size_t)pb.out, last < pb.L ? last : pb.L);
-}
-
 template <int Q, int W>
 __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_store_kernel(float const *__restrict__ pool,
                                                             DcpProfileDev const *__restrict__ profiles,
@@ -175,34 +122,18 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_store_kerne
   DcpProblem const pb = problems[p];
   if (G > 0) block = dcp_num_blocks(pb.L, B) - 1 - (it * G + sub);
   if (block < 0 || block >= dcp_num_blocks(pb.L, B)) return;
-  dcp_store_body<Q, W>(pool, profiles[pb.profile], pb, code_rows, xt_table, arena, ckpt_addr, B, block, sub, out);
-}
-
-// the same for every single-wave class in one launch (see dcp_cost_ckpt_fused_kernel); groups of blocks only
-__global__ __launch_bounds__(64, 2) void dcp_cost_store_fused_kernel(float const *__restrict__ pool,
-                                                                    DcpProfileDev const *__restrict__ profiles,
-                                                                    DcpProblem const *__restrict__ problems,
-                                                                    DcpCodeRow const *__restrict__ code_rows,
-                                                                    float const *__restrict__ xt_table,
-                                                                    unsigned char *__restrict__ arena,
-                                                                    int64_t const *__restrict__ ckpt_addr, int B, int G, int it,
-                                                                    float *__restrict__ out, int nprob)
-{
-  if ((int)blockIdx.x >= nprob * G) return;
-  int const p = (int)blockIdx.x / G, sub = (int)blockIdx.x % G;
-  DcpProblem const pb = problems[p];
-  int const block = dcp_num_blocks(pb.L, B) - 1 - (it * G + sub);
-  if (block < 0) return;
   DcpProfileDev const pf = profiles[pb.profile];
-  switch (pf.Q)
-  {
-  case 1: dcp_store_body<1, 1>(pool, pf, pb, code_rows, xt_table, arena, ckpt_addr, B, block, sub, out); break;
-  case 2: dcp_store_body<2, 1>(pool, pf, pb, code_rows, xt_table, arena, ckpt_addr, B, block, sub, out); break;
-  case 3: dcp_store_body<3, 1>(pool, pf, pb, code_rows, xt_table, arena, ckpt_addr, B, block, sub, out); break;
-  case 4: dcp_store_body<4, 1>(pool, pf, pb, code_rows, xt_table, arena, ckpt_addr, B, block, sub, out); break;
-  case 6: dcp_store_body<6, 1>(pool, pf, pb, code_rows, xt_table, arena, ckpt_addr, B, block, sub, out); break;
-  default: dcp_store_body<8, 1>(pool, pf, pb, code_rows, xt_table, arena, ckpt_addr, B, block, sub, out); break;
-  }
+  CostWave<Q, W, true> w;
+  int const slots = dcp_block_slots(pb.L, B);
+  // integer arithmetic: the engine passes arena = 0 and absolute table addresses in pb.trellis
+  w.tab_sp = dcp_global<float>((uintptr_t)arena + (uintptr_t)pb.trellis) + (size_t)sub * dcp_block_table_floats(pb.L, pf.Kp, B);
+  w.tab_cells = w.tab_sp + (size_t)slots * DCP_SP_STRIDE;
+  w.row_base = block * B;
+  if (block > 0)
+    w.ckpt_in = dcp_global<float const>((uintptr_t)ckpt_addr[pb.out]) + (size_t)(block - 1) * (size_t)dcp_ckpt_floats(pf.Kp, W);
+  w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
+  int const last = B > 0 ? (block + 1) * B + 5 : pb.L;
+  w.run(pb.L, out + 2 * (size_t)pb.out, last < pb.L ? last : pb.L);
 }
 
 // Profiles beyond 4096 positions: one workgroup walks each row strip by strip (StripWave).
@@ -1066,22 +997,6 @@ hipError_t dcp_launch_path_blocks(int cls, DcpLaunch const &a, int64_t const *ck
   case 10: return launch_path_blocks_qw<8, 8>(a, ckpt_addr, B, steps, step_off, nsteps, states);
   default: return hipErrorInvalidValue;
   }
-}
-
-hipError_t dcp_launch_cost_ckpt_fused(DcpLaunch const &a, int64_t const *ckpt_addr, int B)
-{
-  if (a.nprob <= 0) return hipSuccess;
-  hipLaunchKernelGGL(dcp_cost_ckpt_fused_kernel, dim3((unsigned)a.nprob), dim3(64), 0, a.stream, a.pool, a.profiles, a.problems,
-                     a.code_rows, a.xt_table, ckpt_addr, B, a.out, a.nprob);
-  return hipGetLastError();
-}
-
-hipError_t dcp_launch_cost_store_fused(DcpLaunch const &a, int64_t const *ckpt_addr, int B, int G, int it)
-{
-  if (a.nprob <= 0 || G <= 0) return G <= 0 ? hipErrorInvalidValue : hipSuccess;
-  hipLaunchKernelGGL(dcp_cost_store_fused_kernel, dim3((unsigned)a.nprob * (unsigned)G), dim3(64), 0, a.stream, a.pool,
-                     a.profiles, a.problems, a.code_rows, a.xt_table, a.arena, ckpt_addr, B, G, it, a.out, a.nprob);
-  return hipGetLastError();
 }
 
 hipError_t dcp_launch_traceback(DcpLaunch const &a, uint32_t *steps, int64_t const *step_off, int32_t *nsteps,
