@@ -25,7 +25,7 @@ def _line(out):
 
 def test_one_rank_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=1100)
     assert r.returncode == 0, r.stderr
     d = _line(r.stdout)
     assert KEYS <= set(d) and "cpu_baseline" in d
@@ -49,6 +49,10 @@ def test_one_rank_line():
         assert r["traffic"] > 0 and r["hbm"]["frac"] <= 1.0
     assert d["config"]["hits_gathered"] >= 50  # every 10th read carries a planted domain
     assert d["config"]["secondary"]["value"] > 100  # BASELINE configs[1] rides along
+    # a database beyond 4 GB of tables rides along: within a tenth of the headline's rate
+    big = d["config"]["large_db"]
+    assert "error" not in big and big["pool_bytes"] > 2**32 and big["profiles"] == 5000
+    assert 0.85 * d["value"] < big["value"] < 1.1 * d["value"]
     # the database went through the .dcp ingest path
     assert d["config"]["database"]["file_bytes"] > 300e6 and d["config"]["database"]["staging_chunks"] >= 1
     # the whole scan on the same workload (SURVEY 8d's wall definition): slower than the kernels alone, not absurdly so
