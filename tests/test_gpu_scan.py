@@ -176,3 +176,55 @@ def test_two_ranks_scan_their_partitions_and_gather(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = (tmp_path / "multi" / "products.tsv").read_text().splitlines()
     assert lines[1:] == single and len(single) > 0
+
+
+def test_speculative_chains_with_hits_all_along_long_reads(tmp_path, orc):
+    """dcp_scan_run scores every pair's NO-hit window chain in one batch and lets the pairs that did hit walk their real
+    chains: the windows after a hit keep their speculated scores only while they are the same windows (c-core/window.c:21-31
+    moves the next window's start by the hit's end unless that lies more than 4 K before the window's end), the others are
+    scored again in later rounds.  Short real-structured profiles (windows of 1500...8650 nt) against 30 kb reads that
+    carry a domain every ~700 nt, so that hits fall at every offset of their windows, many pairs hit several times in a
+    row and some windows must be re-scored -- every row against the oracle-driven thread_run, and the same file with
+    nothing speculated (every pair round by round)."""
+    from deciphon_amd import synth
+    from deciphon_amd.scan import Batch, Scan, Sequence
+
+    seeds = synth.load_seeds(DCP)
+    Ks = (30, 45, 60, 93, 124, 173)
+    prots = [synth.tile_protein(seeds, K, 29 * i, f"SP{K}") for i, K in enumerate(Ks)]
+    dcp = str(tmp_path / "short.dcp")
+    synth.write_dcp(dcp, prots, 0.01, False, False)
+    rng = np.random.default_rng(2025)
+    reads = []
+    for sid in range(3):
+        x = rng.integers(0, 4, size=30000).astype(np.uint8)
+        at = int(rng.integers(0, 300))
+        while at < 29000:
+            p = prots[int(rng.integers(0, len(prots)))]
+            dom = synth.mutate(synth.back_translate(p["consensus"]), rng, 0.03, 0.01, 0.01)
+            dom = dom[: 30000 - at]
+            x[at : at + len(dom)] = dom
+            at += len(dom) + int(rng.integers(100, 900))
+        reads.append((sid + 1, "".join("ACGT"[v] for v in x)))
+    batch = Batch()
+    for sid, text in reads:
+        batch.add(Sequence(sid, f"r{sid}", text))
+    with Scan(dcp, 0, 1, True, False, False) as scan:
+        scan.run(str(tmp_path / "spec"), batch)
+        rows = scan.products()
+        timing = scan.last_timing()
+    want = oracle_scan(orc, read_dcp(dcp), reads, True, False)
+    assert rows == want
+    assert len(rows) >= 60 and len({r.split("\t")[1] for r in rows}) >= 8  # hits in many windows of the chains
+    assert timing["rounds"] >= 3 and timing["path_passes"] >= len(rows)  # windows were scored again after hits
+    os.environ["DECIPHON_HIP_SPECULATE"] = "0"
+    try:
+        assert run_scan(str(tmp_path / "rounds"), reads, dbfile=dcp) == rows
+    finally:
+        del os.environ["DECIPHON_HIP_SPECULATE"]
+    # ... and with many small cost batches in flight (chunks of 2e6 cells)
+    os.environ["DECIPHON_HIP_CHUNK_CELLS"] = "2e6"
+    try:
+        assert run_scan(str(tmp_path / "chunks"), reads, dbfile=dcp) == rows
+    finally:
+        del os.environ["DECIPHON_HIP_CHUNK_CELLS"]
