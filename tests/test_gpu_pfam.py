@@ -180,7 +180,6 @@ def test_a_database_beyond_4_gb_of_tables(tmp_path, orc):
     with deciphon_amd.Engine(0) as eng:
         eng.load_dcp(dcp)
         eng.commit()
-        os.unlink(dcp)
         assert eng.num_profiles == nprof and eng.pool_bytes > 2**32 and eng.load_chunks >= 15
         assert [eng.core_size(i) for i in (0, nprof // 2, nprof - 1)] == [int(Ks[i]) for i in (0, nprof // 2, nprof - 1)]
         eng.set_sequences(reads)
@@ -207,3 +206,49 @@ def test_a_database_beyond_4_gb_of_tables(tmp_path, orc):
         got = eng.path([tuple(int(v) for v in wins[i])], trellis=True)[0]
         assert np.array_equal(got["state_ids"], ids) and np.array_equal(got["seqsizes"], sizes)
         assert np.array_equal(got["xnodes"], xn) and np.array_equal(got["nodes"], nd)
+
+    # BASELINE configs[4] on the same database (a fifth of Pfam-A's profiles): six 50 kb reads with error-bearing domains
+    # of profiles from the first to the last, all 4200 profiles through dcp_scan_run.  At this size the oracle takes a
+    # SAMPLE -- every row of the eight planted profiles against the oracle-driven thread_run on those eight -- and the
+    # rest is held by properties that do not depend on size: the rows of two balanced partitions concatenate to the
+    # whole scan's (c-core/product.c:63-81), the scan with nothing speculated writes the same file, and rows come in
+    # (profile, read, window) order.
+    from deciphon_amd.scan import Batch, Scan, Sequence
+
+    planted = sorted({0, 1, nprof // 3, nprof // 2, 2 * nprof // 3, nprof - 2, nprof - 1, 777})
+    prots = {i: protein(i) for i in planted}
+    long_reads = []
+    for sid in range(6):
+        x = rng.integers(0, 4, size=50000).astype(np.uint8)
+        for j in range(12):
+            p = prots[planted[(sid + j) % len(planted)]]
+            cons = p["consensus"]
+            a = int(rng.integers(0, max(len(cons) - 220, 1)))
+            dom = synth.mutate(synth.back_translate(cons[a : a + 220]), rng, 0.08, 0.02, 0.02)
+            at = 900 + j * 4000
+            x[at : at + len(dom)] = dom
+        long_reads.append((300 + sid, "".join("ACGT"[v] for v in x)))
+
+    def scan_rows(out, partition=None):
+        batch = Batch()
+        for sid, text in long_reads:
+            batch.add(Sequence(sid, f"seq{sid}", text))
+        with Scan(dcp, 0, 1, True, False, False, partition=partition, balanced=True) as scan:
+            scan.run(str(tmp_path / out), batch)
+            return scan.products()
+
+    whole = scan_rows("whole")
+    acc = {prots[i]["accession"]: i for i in planted}
+    mine = [r for r in whole if r.split("\t")[7] in acc]
+    want = oracle_scan(orc, [SimpleNamespace(**prots[i]) for i in planted], long_reads, True, False,
+                       threads=min(os.cpu_count() or 1, 16))
+    assert mine == want and len(want) >= 40 and len({r.split("\t")[1] for r in want}) >= 4
+    order = [(int(r.split("\t")[7][2:7]), int(r.split("\t")[0]), int(r.split("\t")[1])) for r in whole]
+    assert order == sorted(order)  # accession SYnnnnn.1 = database order
+    assert scan_rows("p0", (0, 0, 2)) + scan_rows("p1", (0, 1, 2)) == whole
+    os.environ["DECIPHON_HIP_SPECULATE"] = "0"
+    try:
+        assert scan_rows("rounds") == whole
+    finally:
+        del os.environ["DECIPHON_HIP_SPECULATE"]
+    os.unlink(dcp)
