@@ -398,18 +398,16 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   char const *beside_env = getenv("DECIPHON_HIP_PATH_BESIDE"); // experiment: path passes beside the cost batches in flight
   bool const path_beside = beside_env && beside_env[0] == '1';
   typedef std::vector<std::pair<int, int>> Chain; // [start, stop) of the windows of a pair that never hits
-  std::map<std::pair<int, int>, Chain> chains;    // by (read length, core size)
-  auto chain_of = [&](int seq_size, int core_size) -> Chain const * {
-    auto it = chains.find({seq_size, core_size});
-    if (it == chains.end())
-    {
-      Chain c;
-      DcpWindow w(seq_size, core_size);
-      while (w.next()) c.emplace_back(w.start, w.stop);
-      it = chains.emplace(std::make_pair(seq_size, core_size), std::move(c)).first;
-    }
-    return &it->second;
+  auto make_chain = [](int seq_size, int core_size, Chain &c) {
+    c.clear();
+    DcpWindow w(seq_size, core_size);
+    while (w.next()) c.emplace_back(w.start, w.stop);
   };
+  // The chains of ONE profile by read length, made as the reads ask for them and dropped with the profile: reads of a
+  // batch often share a length (then this is one chain per profile), but real reads need not -- a cache over all
+  // (length, core size) pairs of a Pfam-sized scan of 1e4 reads of 1e4 lengths would hold 2e8 chains.
+  std::map<int, Chain> chains_of_profile;
+  std::deque<Chain> kept_chains; // the chains of the pairs that hit: they walk them again (PairState::spec)
   // chunks of profiles: small enough for the window table of a chunk (2^21 pairs); the first one is kept short
   // (~4e10 DP cells, a few dozen milliseconds of cost pass) so that the GPU starts early and the host builds and
   // sorts the window list of the second chunk meanwhile.  DECIPHON_HIP_CHUNK_CELLS: cells per chunk (experiments).
@@ -649,11 +647,25 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
           int const K = dcp_hip_profile_core_size(x->eng, p);
           int last_len = -1;
           Chain const *ch = nullptr; // reads of one length follow each other more often than not
+          chains_of_profile.clear();
           for (int s = 0; s < nseq; ++s)
           {
             int const len = (int)batch->seqs[(size_t)s].nt.size();
-            if (len != last_len) ch = len > 0 ? chain_of(last_len = len, K) : nullptr;
-            if (len == 0) last_len = 0;
+            if (len != last_len)
+            {
+              ch = nullptr;
+              if (len > 0)
+              {
+                auto it = chains_of_profile.find(len);
+                if (it == chains_of_profile.end())
+                {
+                  it = chains_of_profile.emplace(len, Chain()).first;
+                  make_chain(len, K, it->second);
+                }
+                ch = &it->second;
+              }
+              last_len = len;
+            }
             if (pass == 1)
             {
               f.base.push_back(n);
@@ -712,7 +724,9 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
         last_pi = pi;
         int const p = p0 + (int)(pi / (size_t)nseq), sq = (int)(pi % (size_t)nseq);
         int const len = (int)batch->seqs[(size_t)sq].nt.size(), K = dcp_hip_profile_core_size(x->eng, p);
-        st.push_back(PairState{p, sq, DcpWindow(len, K), chain_of(len, K), spec_lrt.data() + f.base[pi]});
+        kept_chains.emplace_back();
+        make_chain(len, K, kept_chains.back());
+        st.push_back(PairState{p, sq, DcpWindow(len, K), &kept_chains.back(), spec_lrt.data() + f.base[pi]});
         speculated_of_hit_pairs += f.base[pi + 1] - f.base[pi];
       }
       nwindows += f.wins.size() - speculated_of_hit_pairs; // the windows of the pairs without a hit are final
