@@ -226,9 +226,13 @@ struct dcp_hip
     PinBuf<uint32_t> h_hits;         // ... on the host: the whole list comes back behind the filter
     hipEvent_t done_ev = nullptr;    // an outstanding batch: recorded behind its last device operation
     int n = -1;                      // windows of the outstanding batch, -1: none
-    std::vector<DcpProblem> up_problems; // what the uploads of that batch read
-    std::vector<DcpPack> up_packs;
-    std::vector<int2> up_groups;
+    // the lists go up from pinned memory: a copy from PAGEABLE memory waits for everything the device has been given
+    // (the upload of a batch begun while another was in flight took as long as the rest of that batch's cost pass)
+    PinBuf<DcpProblem> h_problems;
+    PinBuf<DcpPack> h_packs;
+    PinBuf<int2> h_groups;
+    hipEvent_t up_ev = nullptr; // recorded behind the uploads: the pinned lists are not rewritten before
+    bool up_pending = false;
   };
   Bank bank[3];
   int cur = 0;
@@ -320,16 +324,9 @@ struct Staged
   int pg_begin[DCP_NUM_PACK_SHAPES + 1] = {0};
   double cells = 0;
   size_t arena_bytes = 0;
-  // stage() enqueues copies that read the vectors above; whoever owns a Staged may leave early on an error, so the
-  // vectors are not released before the stream has passed those copies (a no-op once the owner has synchronised)
-  hipStream_t pending = nullptr;
   Staged() = default;
   Staged(Staged const &) = delete;
   Staged &operator=(Staged const &) = delete;
-  ~Staged()
-  {
-    if (pending) (void)hipStreamSynchronize(pending);
-  }
 };
 
 // for functions that enqueue copies from vectors of their own: whichever way they leave, the stream has passed the
@@ -585,19 +582,33 @@ int stage(dcp_hip *x, int n, dcp_hip_window const *w, ArenaKind arena_kind, Stag
   HIP_TRY(x, BK(x).d_problems.reserve((size_t)std::max(nu, 1)), DCP_ENOMEM);
   if (!st.packs.empty()) HIP_TRY(x, BK(x).d_packs.reserve(st.packs.size()), DCP_ENOMEM);
   if (!st.pack_groups.empty()) HIP_TRY(x, BK(x).d_pack_groups.reserve(st.pack_groups.size()), DCP_ENOMEM);
-  st.pending = origin;
+  dcp_hip::Bank &B = BK(x);
+  if (B.up_pending) HIP_TRY(x, hipEventSynchronize(B.up_ev), DCP_EFUNCUSE); // the previous lists have gone up
+  B.up_pending = false;
   if (nu)
-    HIP_TRY(x, hipMemcpyAsync(BK(x).d_problems.p, st.problems.data(), (size_t)nu * sizeof(DcpProblem),
-                              hipMemcpyHostToDevice, origin),
+  {
+    HIP_TRY(x, B.h_problems.reserve((size_t)nu), DCP_ENOMEM);
+    memcpy(B.h_problems.p, st.problems.data(), (size_t)nu * sizeof(DcpProblem));
+    HIP_TRY(x, hipMemcpyAsync(B.d_problems.p, B.h_problems.p, (size_t)nu * sizeof(DcpProblem), hipMemcpyHostToDevice, origin),
             DCP_EFUNCUSE);
+  }
   if (!st.packs.empty())
-    HIP_TRY(x, hipMemcpyAsync(BK(x).d_packs.p, st.packs.data(), st.packs.size() * sizeof(DcpPack), hipMemcpyHostToDevice,
+  {
+    HIP_TRY(x, B.h_packs.reserve(st.packs.size()), DCP_ENOMEM);
+    memcpy(B.h_packs.p, st.packs.data(), st.packs.size() * sizeof(DcpPack));
+    HIP_TRY(x, hipMemcpyAsync(B.d_packs.p, B.h_packs.p, st.packs.size() * sizeof(DcpPack), hipMemcpyHostToDevice, origin),
+            DCP_EFUNCUSE);
+  }
+  if (!st.pack_groups.empty())
+  {
+    HIP_TRY(x, B.h_groups.reserve(st.pack_groups.size()), DCP_ENOMEM);
+    memcpy(B.h_groups.p, st.pack_groups.data(), st.pack_groups.size() * sizeof(int2));
+    HIP_TRY(x, hipMemcpyAsync(B.d_pack_groups.p, B.h_groups.p, st.pack_groups.size() * sizeof(int2), hipMemcpyHostToDevice,
                               origin),
             DCP_EFUNCUSE);
-  if (!st.pack_groups.empty())
-    HIP_TRY(x, hipMemcpyAsync(BK(x).d_pack_groups.p, st.pack_groups.data(), st.pack_groups.size() * sizeof(int2),
-                              hipMemcpyHostToDevice, origin),
-            DCP_EFUNCUSE);
+  }
+  HIP_TRY(x, hipEventRecord(B.up_ev, origin), DCP_EFUNCUSE);
+  B.up_pending = true;
   return 0;
 }
 
@@ -816,9 +827,19 @@ struct dcp_hip *dcp_hip_new(int device)
   x->device = device;
   bool ok = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&x->fork_ev, hipEventDisableTiming) == hipSuccess;
+  int prio_low = 0, prio_high = 0;
+  ok = ok && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess;
+  // The multi-wave classes (K > 640) run on high-priority streams.  A workgroup of several wavefronts of 160-256
+  // registers each is placed only where that much is free at once, and beside kernels of small wavefronts (the packed
+  // kernels, 3 or 4 positions per lane) every slot that frees is taken by one of those first: on the headline workload
+  // (6,2) -- 1 % of the cells -- then lasted 317 of the pass's 364 ms and held up the kernel behind it in its hardware
+  // queue (the 32-lane packs, 11 % of the cells, which ran alone at the end).  A high-priority queue is served first.
+  // DECIPHON_HIP_PRIO_FROM: first class (viterbi_kernels.h) that gets one; 99 = none (experiments).
+  int prio_from = 6;
+  if (char const *e = getenv("DECIPHON_HIP_PRIO_FROM")) prio_from = atoi(e);
   for (int c = 0; ok && c < DCP_NUM_CLASSES; ++c)
   {
-    ok = ok && hipStreamCreateWithFlags(&x->qstream[c], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&x->qstream[c], hipStreamNonBlocking, c >= prio_from ? prio_high : 0) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&x->join_ev[c], hipEventDisableTiming) == hipSuccess;
   }
   for (int c = 0; ok && c < DCP_NUM_PACK_SHAPES; ++c)
@@ -831,23 +852,26 @@ struct dcp_hip *dcp_hip_new(int device)
     ok = ok && hipStreamCreateWithFlags(&x->nstream[c], hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&x->njoin_ev[c], hipEventDisableTiming) == hipSuccess;
   }
-  // the path pass: streams of its own, ahead of the cost kernels' in the hardware's eyes -- its few, long-running
-  // wavefronts are bound by latency, not by issue slots, and slip in beside a cost pass in flight
-  int prio_low = 0, prio_high = 0;
-  ok = ok && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess;
+  // The path pass: streams of its own, alternately of high and of normal priority.  The runtime feeds four hardware
+  // queues per priority level and a queue runs its kernels one after the other; a path pass is one chain of kernels per
+  // class (checkpoints, then blocks and traceback in turns), few wavefronts each, bound by latency: on one level the
+  // fifth to seventh chain started only when one of the first four had ended (the pass of 2301 hits of the headline scan:
+  // 55-57 ms, on two levels 48-50).  dcp_scan_run calls it with no cost batch in flight; beside one, the chains on the
+  // normal level queue behind the cost kernels.
   if (char const *e = getenv("DECIPHON_HIP_PATH_STREAM_PRIORITY")) // experiment: 0 = the same priority as the cost streams
     if (e[0] == '0') prio_high = 0;
   ok = ok && hipStreamCreateWithPriority(&x->path_set.stream, hipStreamNonBlocking, prio_high) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&x->path_set.fork_ev, hipEventDisableTiming) == hipSuccess;
   for (int c = 0; ok && c < DCP_NUM_CLASSES; ++c)
   {
-    ok = ok && hipStreamCreateWithPriority(&x->path_set.qstream[c], hipStreamNonBlocking, prio_high) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&x->path_set.qstream[c], hipStreamNonBlocking, c % 2 ? prio_high : 0) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&x->path_set.join_ev[c], hipEventDisableTiming) == hipSuccess;
   }
   ok = ok && hipStreamCreateWithFlags(&x->upload_stream, hipStreamNonBlocking) == hipSuccess;
-  for (int b = 0; ok && b < 2; ++b)
+  for (int b = 0; ok && b < 3; ++b)
   {
-    ok = ok && hipEventCreateWithFlags(&x->bank[b].done_ev, hipEventDisableTiming) == hipSuccess;
+    if (b < 2) ok = ok && hipEventCreateWithFlags(&x->bank[b].done_ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&x->bank[b].up_ev, hipEventDisableTiming) == hipSuccess;
   }
   if (!ok)
   {
@@ -877,6 +901,7 @@ void dcp_hip_del(struct dcp_hip *x)
   for (int b = 0; b < 3; ++b)
   {
     if (x->bank[b].done_ev) (void)hipEventDestroy(x->bank[b].done_ev);
+    if (x->bank[b].up_ev) (void)hipEventDestroy(x->bank[b].up_ev);
   }
   for (int c = 0; c < DCP_NUM_PACK_SHAPES; ++c)
   {
@@ -1344,11 +1369,6 @@ int dcp_hip_cost_hits_begin(struct dcp_hip *x, int n, struct dcp_hip_window cons
             DCP_EFUNCUSE);
     HIP_TRY(x, hipEventRecord(B.done_ev, x->stream), DCP_EFUNCUSE);
   }
-  // `st` goes, but the vectors its uploads may still be reading live on in the bank until the batch is ended
-  st.pending = nullptr;
-  B.up_problems.swap(st.problems);
-  B.up_packs.swap(st.packs);
-  B.up_groups.swap(st.pack_groups);
   B.n = n;
   x->outstanding[x->outstanding[0] >= 0 ? 1 : 0] = bank;
   if (timing)

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "dcp_types.h"
 
@@ -57,6 +58,8 @@ DCP_FN lf lane_shift_up_keep(lf x, lf &keep)
 
 // a uniform value the compiler must hold in a VGPR (so that VALU ops can pair it with
 // an SGPR operand instead of copying the SGPR first)
+// nothing is scheduled across this point
+DCP_FN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 DCP_FN lf lf_pin(float x)
 {
   lf v = x;
@@ -118,33 +121,62 @@ DCP_FN uint32_t read_laneu(lu x, int lane) { return (uint32_t)__builtin_amdgcn_r
 // per slot is enough.
 enum { GS_M, GS_I, GS_D, GS_E, GS_F, GS_X, GS_T0, GS_T1, GS_X0, GS_X1, GS_SLOTS };
 
-// Values parked in LDS between their uses (CostWave with 8 positions per lane): chunk j of a lane
-// sits at ((wave*4 + slot)*Q/4 + j)*64 + lane float4s, so a wave reads 64 consecutive float4s.
-#define DCP_STASH_SLOTS(W_) ((W_) > 1 ? 8 : 4)
-template <int Q, int W> DCP_FN float4 *dcp_stash_mem()
+// Values parked in LDS between their uses (CostWave, POLICY bits 2 / 4): chunk j of a lane sits at
+// ((wave*SLOTS + slot)*CHUNKS + j)*64 + lane chunks -- float4s, float2s or floats, the widest that divides Q -- so a
+// wave reads 64 consecutive chunks.
+template <int Q> struct DcpStashChunk
 {
-  static_assert(Q % 4 == 0, "whole float4 chunks");
-  __shared__ float4 mem[W * DCP_STASH_SLOTS(W) * (Q / 4) * 64];
+  static constexpr int N = Q % 4 == 0 ? 4 : Q % 2 == 0 ? 2 : 1; // floats per chunk
+  typedef typename std::conditional<N == 4, float4, typename std::conditional<N == 2, float2, float>::type>::type type;
+};
+template <int Q, int W, int SLOTS> DCP_FN typename DcpStashChunk<Q>::type *dcp_stash_mem()
+{
+  __shared__ typename DcpStashChunk<Q>::type mem[W * SLOTS * (Q / DcpStashChunk<Q>::N) * 64];
   return mem;
 }
-template <int Q, int W> DCP_FN void dcp_stash(int wave, lu lane, int slot, lf const (&v)[Q])
+template <int N> DCP_FN void dcp_chunk_get(typename std::conditional<N == 4, float4, typename std::conditional<N == 2, float2, float>::type>::type const &t, lf *v)
 {
-  float4 *mem = dcp_stash_mem<Q, W>() + (size_t)(wave * DCP_STASH_SLOTS(W) + slot) * (Q / 4) * 64 + (lane & 63u);
-#pragma unroll
-  for (int j = 0; j < Q / 4; ++j) mem[j * 64] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-}
-template <int Q, int W> DCP_FN void dcp_unstash(int wave, lu lane, int slot, lf (&v)[Q])
-{
-  float4 const *mem = dcp_stash_mem<Q, W>() + (size_t)(wave * DCP_STASH_SLOTS(W) + slot) * (Q / 4) * 64 + (lane & 63u);
-#pragma unroll
-  for (int j = 0; j < Q / 4; ++j)
+  if constexpr (N == 1)
+    v[0] = t;
+  else
   {
-    float4 const t = mem[j * 64];
-    v[4 * j] = t.x;
-    v[4 * j + 1] = t.y;
-    v[4 * j + 2] = t.z;
-    v[4 * j + 3] = t.w;
+    v[0] = t.x;
+    v[1] = t.y;
+    if constexpr (N == 4)
+    {
+      v[2] = t.z;
+      v[3] = t.w;
+    }
   }
+}
+template <int Q, int W, int SLOTS> DCP_FN void dcp_stash(int wave, lu lane, int slot, lf const (&v)[Q])
+{
+  constexpr int N = DcpStashChunk<Q>::N;
+  auto *mem = dcp_stash_mem<Q, W, SLOTS>() + (size_t)(wave * SLOTS + slot) * (Q / N) * 64 + (lane & 63u);
+#pragma unroll
+  for (int j = 0; j < Q / N; ++j)
+  {
+    if constexpr (N == 4)
+      mem[j * 64] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    else if constexpr (N == 2)
+      mem[j * 64] = make_float2(v[2 * j], v[2 * j + 1]);
+    else
+      mem[j * 64] = v[j];
+  }
+}
+template <int Q, int W, int SLOTS> DCP_FN void dcp_unstash(int wave, lu lane, int slot, lf (&v)[Q])
+{
+  constexpr int N = DcpStashChunk<Q>::N;
+  auto const *mem = dcp_stash_mem<Q, W, SLOTS>() + (size_t)(wave * SLOTS + slot) * (Q / N) * 64 + (lane & 63u);
+#pragma unroll
+  for (int j = 0; j < Q / N; ++j) dcp_chunk_get<N>(mem[j * 64], v + N * j);
+}
+// chunk j alone (DcpStashChunk<Q>::N positions): for users that walk an array once, a few positions at a time
+template <int Q, int W, int SLOTS>
+DCP_FN void dcp_unstash_chunk(int wave, lu lane, int slot, int j, lf (&v)[DcpStashChunk<Q>::N])
+{
+  constexpr int N = DcpStashChunk<Q>::N;
+  dcp_chunk_get<N>(dcp_stash_mem<Q, W, SLOTS>()[((size_t)(wave * SLOTS + slot) * (Q / N) + j) * 64 + (lane & 63u)], v);
 }
 
 template <int W> struct Group;
@@ -159,8 +191,12 @@ template <> struct Group<1>
   DCP_FN void put_lanes4(int, lf) {}
   DCP_FN void put_any(int, lm) {}
   template <int Q> DCP_FN void put_tdd(lf const (&)[Q]) {}
-  template <int Q> DCP_FN void stash_q(int slot, lf const (&v)[Q]) { dcp_stash<Q, 1>(0, lane, slot, v); }
-  template <int Q> DCP_FN void unstash_q(int slot, lf (&v)[Q]) { dcp_unstash<Q, 1>(0, lane, slot, v); }
+  template <int Q, int SLOTS> DCP_FN void stash_q(int slot, lf const (&v)[Q]) { dcp_stash<Q, 1, SLOTS>(0, lane, slot, v); }
+  template <int Q, int SLOTS> DCP_FN void unstash_q(int slot, lf (&v)[Q]) { dcp_unstash<Q, 1, SLOTS>(0, lane, slot, v); }
+  template <int Q, int SLOTS> DCP_FN void unstash_chunk(int slot, int j, lf (&v)[DcpStashChunk<Q>::N])
+  {
+    dcp_unstash_chunk<Q, 1, SLOTS>(0, lane, slot, j, v);
+  }
   DCP_FN void put_count(int, lm) {}
   DCP_FN void sync() {}
   DCP_FN lf get_shift(int, lf x, float fill) { return lane_shift_up(x, fill); }
@@ -231,8 +267,8 @@ template <int W> struct Group
     return __int_as_float(
         __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
   }
-  template <int Q> DCP_FN void stash_q(int slot, lf const (&v)[Q]) { dcp_stash<Q, W>(wave, lane, slot, v); }
-  template <int Q> DCP_FN void unstash_q(int slot, lf (&v)[Q]) { dcp_unstash<Q, W>(wave, lane, slot, v); }
+  template <int Q, int SLOTS> DCP_FN void stash_q(int slot, lf const (&v)[Q]) { dcp_stash<Q, W, SLOTS>(wave, lane, slot, v); }
+  template <int Q, int SLOTS> DCP_FN void unstash_q(int slot, lf (&v)[Q]) { dcp_unstash<Q, W, SLOTS>(wave, lane, slot, v); }
   DCP_FN bool seg_any(lm m) const { return wave_any(m); }
   DCP_FN lm seg_first() const { return (lane & 63u) == 0u; }
   template <int Q> DCP_FN void put_tdd(lf const (&DD)[Q])
@@ -451,6 +487,16 @@ template <> DCP_FN void load_q<8>(float const *__restrict__ row, lu lane, lf (&o
   out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
 }
 
+template <> DCP_FN void load_q<10>(float const *__restrict__ row, lu lane, lf (&out)[10])
+{
+  float2 const *p = reinterpret_cast<float2 const *>(row + (size_t)lane * 10); // 40-byte elements, 8-byte aligned
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+  {
+    float2 const a = p[j];
+    out[2 * j] = a.x; out[2 * j + 1] = a.y;
+  }
+}
 // ---- emission rows: { null, bg, 0, 0, match[0..Kp) } behind one scalar byte offset ----
 // Addressed through a buffer resource: the row offset travels in an SGPR (soffset) and
 // the lane's own offset in one VGPR computed once, so a row read costs no VALU at all.
@@ -540,6 +586,16 @@ template <> DCP_FN void load_row_q<8>(RowSrc const &r, lu voff, uint32_t soff, l
   out[6] = __uint_as_float(b.z); out[7] = __uint_as_float(b.w);
 }
 
+template <> DCP_FN void load_row_q<10>(RowSrc const &r, lu voff, uint32_t soff, lf (&out)[10])
+{
+  dcp_u32x4 const a = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, voff, soff, 0);
+  dcp_u32x4 const b = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, voff + 16u, soff, 0);
+  dcp_u32x2 const c = __builtin_amdgcn_raw_buffer_load_b64(r.rsrc, voff + 32u, soff, 0);
+  out[0] = __uint_as_float(a.x); out[1] = __uint_as_float(a.y); out[2] = __uint_as_float(a.z);
+  out[3] = __uint_as_float(a.w); out[4] = __uint_as_float(b.x); out[5] = __uint_as_float(b.y);
+  out[6] = __uint_as_float(b.z); out[7] = __uint_as_float(b.w); out[8] = __uint_as_float(c.x);
+  out[9] = __uint_as_float(c.y);
+}
 // one DP-table row plane: the lane's Q values at row[lane*Q ..], rows padded to Kp
 template <int Q> DCP_FN void store_q(float *__restrict__ row, lu lane, lf const (&v)[Q])
 {

@@ -409,8 +409,10 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
   std::map<int, Chain> chains_of_profile;
   std::deque<Chain> kept_chains; // the chains of the pairs that hit: they walk them again (PairState::spec)
   // chunks of profiles: small enough for the window table of a chunk (2^21 pairs); the first one is kept short
-  // (~4e10 DP cells, a few dozen milliseconds of cost pass) so that the GPU starts early and the host builds and
-  // sorts the window list of the second chunk meanwhile.  DECIPHON_HIP_CHUNK_CELLS: cells per chunk (experiments).
+  // (~1e10 DP cells, a dozen milliseconds of cost pass) so that the GPU starts early and the host builds and sorts
+  // the window list of the second chunk meanwhile (14 ms for the headline's 416 k windows; 4e10 cells while the upload
+  // of that list still waited for the device, profiles/r03_exp_register_policy.txt: 0.497-0.499 -> 0.493-0.495 s).
+  // DECIPHON_HIP_CHUNK_CELLS: cells per chunk (experiments).
   std::vector<std::pair<int, int>> chunks;
   {
     double read_nt = 0;
@@ -419,11 +421,12 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     int const by_pairs = nseq > 0 ? (int)std::max<size_t>(1, max_pairs / (size_t)nseq) : std::max(nprof, 1);
     char const *cells_env = getenv("DECIPHON_HIP_CHUNK_CELLS");
     double const chunk_cells = cells_env ? atof(cells_env) : 0.0;
+    double const first_cells = 1.0e10;
     for (int p0 = 0; p0 < nprof;)
     {
       int p1 = p0;
       double cells = 0;
-      double const limit = chunk_cells > 0 ? chunk_cells : p0 == 0 ? 4.0e10 : 1.0e300;
+      double const limit = chunk_cells > 0 ? chunk_cells : p0 == 0 ? first_cells : 1.0e300;
       while (p1 < nprof && p1 - p0 < by_pairs && (p1 == p0 || cells < limit))
         cells += read_nt * (double)dcp_hip_profile_core_size(x->eng, p1++);
       chunks.emplace_back(p0, p1);
@@ -444,7 +447,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     float lrt;
   };
   std::deque<PairState> st;                // pairs that need more than their speculated scores
-  std::deque<std::vector<float>> spec_store; // spec_lrt of every chunk: alive until the last pair is done
+  std::deque<std::vector<float>> kept_lrt; // ... and the speculated lrt of their chains' windows (PairState::spec_lrt)
   std::vector<Work> need_cost, need_path;
 
   // moves a pair to its next window that needs work: a path pass (a speculated window that passed the filter) or a
@@ -711,23 +714,24 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
       ph.cost += ph.lap();
       if (x->interrupted) continue; // (the batches still in flight are ended and dropped)
       if (next < nchunks && (rc = begin_chunk(next++))) return rc;
-      spec_store.emplace_back(f.wins.size(), -1.0f);
-      std::vector<float> &spec_lrt = spec_store.back();
       size_t speculated_of_hit_pairs = 0, first_new = st.size();
       size_t last_pi = (size_t)-1;
       for (int h = 0; h < nh; ++h) // hit_index ascends: the hits of a pair are neighbours
       {
         size_t const wi = (size_t)hit_index[(size_t)h];
-        spec_lrt[wi] = lrts[(size_t)h];
         size_t const pi = (size_t)(std::upper_bound(f.base.begin(), f.base.end(), wi) - f.base.begin()) - 1;
-        if (pi == last_pi) continue;
-        last_pi = pi;
-        int const p = p0 + (int)(pi / (size_t)nseq), sq = (int)(pi % (size_t)nseq);
-        int const len = (int)batch->seqs[(size_t)sq].nt.size(), K = dcp_hip_profile_core_size(x->eng, p);
-        kept_chains.emplace_back();
-        make_chain(len, K, kept_chains.back());
-        st.push_back(PairState{p, sq, DcpWindow(len, K), &kept_chains.back(), spec_lrt.data() + f.base[pi]});
-        speculated_of_hit_pairs += f.base[pi + 1] - f.base[pi];
+        if (pi != last_pi) // a pair's first hit: its chain and the (so far hit-less) scores of the chain's windows
+        {
+          last_pi = pi;
+          int const p = p0 + (int)(pi / (size_t)nseq), sq = (int)(pi % (size_t)nseq);
+          int const len = (int)batch->seqs[(size_t)sq].nt.size(), K = dcp_hip_profile_core_size(x->eng, p);
+          kept_chains.emplace_back();
+          make_chain(len, K, kept_chains.back());
+          kept_lrt.emplace_back(f.base[pi + 1] - f.base[pi], -1.0f);
+          st.push_back(PairState{p, sq, DcpWindow(len, K), &kept_chains.back(), kept_lrt.back().data()});
+          speculated_of_hit_pairs += f.base[pi + 1] - f.base[pi];
+        }
+        kept_lrt.back()[wi - f.base[pi]] = lrts[(size_t)h];
       }
       nwindows += f.wins.size() - speculated_of_hit_pairs; // the windows of the pairs without a hit are final
       for (size_t i = first_new; i < st.size(); ++i) advance(i);

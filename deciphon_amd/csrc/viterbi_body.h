@@ -49,15 +49,32 @@ constexpr int dcp_lazy_turns(int Q) { return Q >= DCP_LAZY_POSITIONS ? 1 : (DCP_
 // STORE = true additionally writes every row's final values to a DP table in HBM
 // (cells[l][{M,I,D}][Kp] and specials[l][8] = N,B,J,E,C) for the traceback of
 // traceback.h -- the fast path pass.
-template <int Q, int W, bool STORE = false> struct CostWave
+// How a shape trades registers for LDS and prefetch distance (POLICY, bits):
+//   1  the next row's emissions are asked for behind the D chain instead of before it: MD, DD and D are then not alive
+//      beside them (Q registers fewer at the peak for each of the five emission lengths);
+//   2  MD, DD, II, MI wait in LDS between their uses (a row needs each for a few instructions);
+//   4  all eight transition arrays do, and a single wave takes the six of the fold back a few positions at a time.
+// Defaults: (8,1) parks four arrays (260 -> under 256 VGPRs: two waves per SIMD instead of one), the multi-wave shapes of
+// 8 positions all eight (the exchange needs room), single waves beyond 8 positions all of it (10 positions: 226 VGPRs).
+#ifndef DCP_SHAPE_POLICY
+#define DCP_SHAPE_POLICY(Q, W) ((W) == 1 ? ((Q) > 8 ? 7 : (Q) == 8 ? 2 : 0) : ((Q) >= 8 ? 6 : 0))
+#endif
+// The bulk cost kernels (dcp_cost_kernel) run (4,1) and (5,1) with bit 1 as well: 147 -> 128 VGPRs puts a fourth
+// wavefront on every SIMD, and (5,1) fits three without spilling inside the row loop (viterbi_kernels.hip,
+// DCP_COST_WAVES).  The path pass's kernels -- a few lone wavefronts that wait out every load -- keep the early request.
+#ifndef DCP_COST_POLICY
+#define DCP_COST_POLICY(Q, W) (DCP_SHAPE_POLICY(Q, W) | ((W) == 1 && ((Q) == 4 || (Q) == 5) ? 1 : 0))
+#endif
+template <int Q, int W, bool STORE = false, int POLICY = DCP_SHAPE_POLICY(Q, W)> struct CostWave
 {
   // lazy D->D turns taken before the first vote: a turn is 2Q + 2 instructions straight-line, a vote costs a
   // ballot, a scalar branch and the register copies of a loop.  Extra turns change nothing (min is idempotent).
   static constexpr int TURNS = dcp_lazy_turns(Q);
-  // Q = 8: MD, DD, II, MI wait in LDS between their uses (a row needs them for a few instructions
-  // each), which brings the kernel from 260 to under 256 VGPRs -- two waves per SIMD instead of one
-  static constexpr bool STASH = Q >= 8;
-  static constexpr bool STASH6 = STASH && W > 1; // the multi-wave exchange needs more room: all eight
+  static constexpr bool LATE_FETCH = (POLICY & 1) != 0;
+  static constexpr bool STASH = (POLICY & 6) != 0;
+  static constexpr bool STASH6 = (POLICY & 4) != 0;
+  static constexpr bool CHUNKED = STASH6 && W == 1;
+  static constexpr int SLOTS = STASH6 ? 8 : 4; // arrays parked per wave
   Group<W> g;
   float *__restrict__ tab_cells = nullptr; // [(L+1)][3][Kp]
   float *__restrict__ tab_sp = nullptr;    // [(L+1)][DCP_SP_STRIDE]
@@ -158,16 +175,16 @@ template <int Q, int W, bool STORE = false> struct CostWave
     g.put_tdd(DD); // W > 1: what running through a whole wave of delete states costs (row())
     if constexpr (STASH)
     {
-      g.template stash_q<Q>(0, MD);
-      g.template stash_q<Q>(1, DD);
-      g.template stash_q<Q>(2, II);
-      g.template stash_q<Q>(3, MI);
+      g.template stash_q<Q, SLOTS>(0, MD);
+      g.template stash_q<Q, SLOTS>(1, DD);
+      g.template stash_q<Q, SLOTS>(2, II);
+      g.template stash_q<Q, SLOTS>(3, MI);
       if constexpr (STASH6)
       {
-        g.template stash_q<Q>(4, IM);
-        g.template stash_q<Q>(5, DM);
-        g.template stash_q<Q>(6, BM);
-        g.template stash_q<Q>(7, MM);
+        g.template stash_q<Q, SLOTS>(4, IM);
+        g.template stash_q<Q, SLOTS>(5, DM);
+        g.template stash_q<Q, SLOTS>(6, BM);
+        g.template stash_q<Q, SLOTS>(7, MM);
       }
     }
     ET = xt[DCP_ET];
@@ -222,7 +239,8 @@ template <int Q, int W, bool STORE = false> struct CostWave
               Spre[DCP_SL(P, 2)] + nil[1], Spre[DCP_SL(P, 1)] + nil[0]);
 
     // emissions of this row are consumed: fetch the next row's behind the rest
-    if (l < L) fetch(l + 2, L);
+    if constexpr (!LATE_FETCH)
+      if (l < L) fetch(l + 2, L);
 
     lf m = M[0];
 #pragma unroll
@@ -232,8 +250,8 @@ template <int Q, int W, bool STORE = false> struct CostWave
     float N, J;
     if constexpr (STASH)
     {
-      g.template unstash_q<Q>(0, MD);
-      g.template unstash_q<Q>(1, DD);
+      g.template unstash_q<Q, SLOTS>(0, MD);
+      g.template unstash_q<Q, SLOTS>(1, DD);
     }
     if constexpr (W == 1)
     {
@@ -364,26 +382,64 @@ template <int Q, int W, bool STORE = false> struct CostWave
     }
 
     // fold row l into the ring (slot P held row l-5, no longer needed)
-    if constexpr (STASH)
+    if constexpr (LATE_FETCH)
     {
-      g.template unstash_q<Q>(2, II);
-      g.template unstash_q<Q>(3, MI);
-      if constexpr (STASH6)
+      // the next row's emissions are asked for only now (ten positions per lane with MD, DD and D alive beside them
+      // would not fit 256 registers: 23 scratch accesses per row)
+      sched_fence();
+      if (l < L) fetch(l + 2, L);
+      sched_fence();
+    }
+    if constexpr (CHUNKED)
+    {
+      // more than eight positions in one wave: the six arrays of the fold come back a few positions at a time
+      constexpr int N = DcpStashChunk<Q>::N;
+#pragma unroll
+      for (int j = 0; j < Q / N; ++j)
       {
-        g.template unstash_q<Q>(4, IM);
-        g.template unstash_q<Q>(5, DM);
-        g.template unstash_q<Q>(6, BM);
-        g.template unstash_q<Q>(7, MM);
+        lf bm[N], mm[N], im[N], dm[N], ii[N], mi[N];
+        g.template unstash_chunk<Q, SLOTS>(2, j, ii);
+        g.template unstash_chunk<Q, SLOTS>(3, j, mi);
+        g.template unstash_chunk<Q, SLOTS>(4, j, im);
+        g.template unstash_chunk<Q, SLOTS>(5, j, dm);
+        g.template unstash_chunk<Q, SLOTS>(6, j, bm);
+        g.template unstash_chunk<Q, SLOTS>(7, j, mm);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+        {
+          int const q = N * j + i;
+          lf const Ml = q ? M[q ? q - 1 : 0] : Msh0;
+          lf const Il = q ? I[q ? q - 1 : 0] : Ish0;
+          lf const Dl = q ? D[q ? q - 1 : 0] : Dsh0;
+          Mpre[P][q] = lmin3(B + bm[i], Ml + mm[i], lmin(Il + im[i], Dl + dm[i]));
+          Ipre[P][q] = lmin(I[q] + ii[i], M[q] + mi[i]);
+        }
+        sched_fence(); // (the scheduler would bring every chunk's LDS reads up front: 36 registers more at the peak)
       }
     }
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
+    else if constexpr (STASH)
     {
-      lf const Ml = q ? M[q ? q - 1 : 0] : Msh0;
-      lf const Il = q ? I[q ? q - 1 : 0] : Ish0;
-      lf const Dl = q ? D[q ? q - 1 : 0] : Dsh0;
-      Mpre[P][q] = lmin3(B + BM[q], Ml + MM[q], lmin(Il + IM[q], Dl + DM[q]));
-      Ipre[P][q] = lmin(I[q] + II[q], M[q] + MI[q]);
+      g.template unstash_q<Q, SLOTS>(2, II);
+      g.template unstash_q<Q, SLOTS>(3, MI);
+      if constexpr (STASH6)
+      {
+        g.template unstash_q<Q, SLOTS>(4, IM);
+        g.template unstash_q<Q, SLOTS>(5, DM);
+        g.template unstash_q<Q, SLOTS>(6, BM);
+        g.template unstash_q<Q, SLOTS>(7, MM);
+      }
+    }
+    if constexpr (!CHUNKED)
+    {
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+      {
+        lf const Ml = q ? M[q ? q - 1 : 0] : Msh0;
+        lf const Il = q ? I[q ? q - 1 : 0] : Ish0;
+        lf const Dl = q ? D[q ? q - 1 : 0] : Dsh0;
+        Mpre[P][q] = lmin3(B + BM[q], Ml + MM[q], lmin(Il + IM[q], Dl + DM[q]));
+        Ipre[P][q] = lmin(I[q] + II[q], M[q] + MI[q]);
+      }
     }
     Spre[P] = lmin(lf_splat(E) + sa, X + sb);
     if (STORE)

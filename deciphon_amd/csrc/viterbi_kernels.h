@@ -41,7 +41,9 @@ struct DcpLaunch
 };
 
 hipError_t dcp_launch_cost(int cls, DcpLaunch const &a);
-int dcp_class_narrow_limit(int cls);                             // core sizes up to it run one position per lane less (0: none)
+// core sizes up to it have a cost kernel of their own on the class's layout (0: none): (5,1) below (6,1), (7,1) below
+// (8,1), and K <= 640 as ONE wavefront of ten positions per lane instead of (6,2)'s two
+int dcp_class_narrow_limit(int cls);
 hipError_t dcp_launch_cost_narrow(int cls, DcpLaunch const &a); // cost pass of those windows
 hipError_t dcp_launch_path(int cls, DcpLaunch const &a);
 // trellis_unzip of every problem of a.problems (all classes): steps[step_off[out] .. step_off[out+1]) is the

@@ -36,18 +36,21 @@ __device__ __forceinline__ int dcp_xcd_remap(int b, int n)
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
-// (tried: holding Q = 3 / 4 to 96 / 128 VGPRs for 5 / 4 waves per SIMD -- the 6-7 scratch reloads per row cost
-// far more than the occupancy gives: 881 -> 620 GCUPS at K = 173, 1000 -> 878 at K = 256)
 // Wavefronts per SIMD the register allocator must leave room for.  A wavefront issues a VALU every ~7.5 cycles
 // whatever its instruction-level parallelism (profiles/r02_valu_rates.txt), so two wavefronts per SIMD cap the
-// issue rate at 640 G/s and three at 729: (5,1) is held to 168 VGPRs -- what it spills then lies outside the row
-// loop (K = 300: 796 -> 838 GCUPS).  The same bound on (6,1), (7,1) puts 26-55 scratch loads into every row, on
-// (3,1) / (4,1) / the packed kernels 7-10 (slower: profiles/r02_exp_trans_stash_occupancy.txt).
+// issue rate at 640 G/s and three at 729.  Holding a shape to fewer registers by the bound alone spills into the row
+// loop (Q = 3 / 4 to 96 / 128 VGPRs: 6-7 scratch reloads per row, 881 -> 620 GCUPS at K = 173, 1000 -> 878 at K = 256;
+// (6,1), (7,1) to 168: 26-55 per row -- profiles/r02_exp_trans_stash_occupancy.txt).  Asking for the next row's
+// emissions later in the row (DCP_COST_POLICY bit 1, viterbi_body.h) frees Q registers per emission length at the
+// peak instead: (4,1) 147 -> 128 VGPRs = four wavefronts per SIMD instead of three (K = 256: 1102 -> 1199 GCUPS),
+// (5,1) fits 168 with nothing spilled inside the loop (K = 300: 961 -> 1006), and ten positions per lane fit one
+// wavefront at all ((10,1), 226 VGPRs: K = 513..640 run 32-38 % faster than as two wavefronts of five).  Where the
+// wavefronts per SIMD stay what they were it brings nothing ((3,1), (6,1), (7,1): profiles/r03_exp_register_policy.txt).
 #ifndef DCP_COST_WAVES
-#define DCP_COST_WAVES(Q, W) ((W) == 1 && (Q) == 5 ? 3 : (Q) >= 8 ? 2 : 1)
+#define DCP_COST_WAVES(Q, W) ((W) == 1 && (Q) == 4 ? 4 : (W) == 1 && (Q) == 5 ? 3 : (Q) >= 8 ? 2 : 1)
 #endif
-template <int Q, int W>
-__global__ __launch_bounds__(64 * W, DCP_COST_WAVES(Q, W)) void dcp_cost_kernel(float const *__restrict__ pool,
+template <int Q, int W, int POLICY = DCP_COST_POLICY(Q, W), int WAVES = DCP_COST_WAVES(Q, W)>
+__global__ __launch_bounds__(64 * W, WAVES) void dcp_cost_kernel(float const *__restrict__ pool,
                                                       DcpProfileDev const *__restrict__ profiles,
                                                       DcpProblem const *__restrict__ problems,
                                                       DcpCodeRow const *__restrict__ code_rows,
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(64 * W, DCP_COST_WAVES(Q, W)) void dcp_cost_kernel(
   int const p = dcp_xcd_remap((int)blockIdx.x, nprob);
   DcpProblem const pb = problems[p];
   DcpProfileDev const pf = profiles[pb.profile];
-  CostWave<Q, W> w;
+  CostWave<Q, W, false, POLICY> w;
   w.init(pool, pf, code_rows + pb.code_row, xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE);
   w.run(pb.L, out + 2 * (size_t)pb.out);
 }
@@ -556,11 +559,12 @@ __global__ __launch_bounds__(64) void dcp_cost_kernel_fused(float const *__restr
 }
 
 // Several windows of one profile per wavefront (viterbi_pack.h): one workgroup = one wavefront = one DcpPack.
+// (four positions per lane with the next row's operands asked for late: 180 -> 155 VGPRs, three wavefronts per SIMD)
 #ifndef DCP_PACK_WAVES
-#define DCP_PACK_WAVES(Q) 1
+#define DCP_PACK_WAVES(Q) ((Q) == 4 ? 3 : 1)
 #endif
-template <int Q, int S>
-__global__ __launch_bounds__(64, DCP_PACK_WAVES(Q)) void dcp_cost_pack_kernel(float const *__restrict__ pool,
+template <int Q, int S, bool LATE = DCP_PACK_LATE(Q), int WAVES = DCP_PACK_WAVES(Q)>
+__global__ __launch_bounds__(64, WAVES) void dcp_cost_pack_kernel(float const *__restrict__ pool,
                                                            DcpProfileDev const *__restrict__ profiles,
                                                            DcpPack const *__restrict__ packs,
                                                            DcpCodeRow const *__restrict__ code_rows, uint32_t ncode_rows,
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(64, DCP_PACK_WAVES(Q)) void dcp_cost_pack_kernel(fl
   if ((int)blockIdx.x >= npack) return;
   DcpPack const &pk = packs[dcp_xcd_remap((int)blockIdx.x, npack)];
   DcpProfileDev const pf = profiles[pk.profile];
-  PackWave<Q, S> w;
+  PackWave<Q, S, dcp_lazy_turns(Q), 0, LATE> w;
   w.init(pool, pf, code_rows, ncode_rows, xt_table, pk);
   w.run(pk.Lmax, out, pk, xt_table);
 }
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(64, DCP_PACK_WAVES(Q)) void dcp_cost_pack_kernel(fl
 // wavefronts = WG packs of ONE profile (groups[blockIdx] = first pack, number of packs) copies the first
 // DCP_PACK_LDS_ROWS(NLDS) rows of the profile's table -- header and position columns -- once, and every
 // wavefront gathers those operands from there.
-template <int Q, int S, int WG, int NLDS>
+template <int Q, int S, int WG, int NLDS, bool LATE = DCP_PACK_LATE(Q)>
 __global__ __launch_bounds__(64 * WG) void dcp_cost_pack_lds_kernel(float const *__restrict__ pool,
                                                                    DcpProfileDev const *__restrict__ profiles,
                                                                    DcpPack const *__restrict__ packs,
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(64 * WG) void dcp_cost_pack_lds_kernel(float const 
   int const wave = (int)(threadIdx.x >> 6);
   if (wave >= grp.y) return; // no barrier follows
   DcpPack const &pk = packs[grp.x + wave];
-  PackWave<Q, S, dcp_lazy_turns(Q), NLDS> w;
+  PackWave<Q, S, dcp_lazy_turns(Q), NLDS, LATE> w;
   w.init(pool, pf, code_rows, ncode_rows, xt_table, pk, (lds_float const *)table);
   w.run(pk.Lmax, out, pk, xt_table);
 }
@@ -817,10 +821,11 @@ hipError_t dcp_launch_unzip(DcpLaunch const &a, uint32_t *steps, int64_t const *
   return hipGetLastError();
 }
 
-template <int Q, int W> static hipError_t launch_cost_qw(DcpLaunch const &a)
+template <int Q, int W, int POLICY = DCP_COST_POLICY(Q, W), int WAVES = DCP_COST_WAVES(Q, W)>
+static hipError_t launch_cost_qw(DcpLaunch const &a)
 {
-  hipLaunchKernelGGL((dcp_cost_kernel<Q, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool, a.profiles,
-                     a.problems, a.code_rows, a.xt_table, a.out, a.nprob);
+  hipLaunchKernelGGL((dcp_cost_kernel<Q, W, POLICY, WAVES>), dim3((unsigned)a.nprob), dim3(64 * W), 0, a.stream, a.pool,
+                     a.profiles, a.problems, a.code_rows, a.xt_table, a.out, a.nprob);
   return hipGetLastError();
 }
 
@@ -895,9 +900,11 @@ hipError_t dcp_launch_cost(int cls, DcpLaunch const &a)
 }
 
 // The classes whose rows are padded to 384, 512 and 768 columns: a profile that fits with one position per lane
-// less -- K <= 320 in (5,1) instead of (6,1), K <= 448 in (7,1) instead of (8,1), K <= 640 in (5,2) instead of
-// (6,2) -- runs that way on the same tables (it reads the first 64 Q W columns of a row): a sixth or an eighth
-// fewer instructions per row.  The engine sorts those windows to the front of their class.
+// less -- K <= 320 in (5,1) instead of (6,1), K <= 448 in (7,1) instead of (8,1) -- runs that way on the same
+// tables (it reads the first 64 Q W columns of a row): a sixth or an eighth fewer instructions per row.  K <= 640 on
+// the 768-column layout runs as ONE wavefront of ten positions per lane, (10,1), instead of two of five: no barrier
+// and no exchange per row, 325 instead of 2 x 242 VALU instructions (K = 520 / 576 / 640: 530 / 585 / 651 -> 715 /
+// 810 / 857 GCUPS).  The engine sorts those windows to the front of their class.
 int dcp_class_narrow_limit(int cls) { return cls == 4 ? 320 : cls == 5 ? 448 : cls == 6 ? 640 : 0; }
 
 hipError_t dcp_launch_cost_narrow(int cls, DcpLaunch const &a)
@@ -907,7 +914,7 @@ hipError_t dcp_launch_cost_narrow(int cls, DcpLaunch const &a)
   {
   case 4: return launch_cost_qw<5, 1>(a);
   case 5: return launch_cost_qw<7, 1>(a);
-  case 6: return launch_cost_qw<5, 2>(a);
+  case 6: return launch_cost_qw<10, 1>(a); // one wavefront on the two-wave layout
   default: return hipErrorInvalidValue;
   }
 }
@@ -1028,10 +1035,11 @@ void dcp_pack_shape(int shape, int *Q, int *S)
   *S = pack_S[shape];
 }
 
-template <int Q, int S> static hipError_t launch_pack_qs(DcpLaunch const &a, DcpPack const *packs, int npack, uint32_t ncode_rows)
+template <int Q, int S, bool LATE = DCP_PACK_LATE(Q), int WAVES = DCP_PACK_WAVES(Q)>
+static hipError_t launch_pack_qs(DcpLaunch const &a, DcpPack const *packs, int npack, uint32_t ncode_rows)
 {
-  hipLaunchKernelGGL((dcp_cost_pack_kernel<Q, S>), dim3((unsigned)npack), dim3(64), 0, a.stream, a.pool, a.profiles, packs,
-                     a.code_rows, ncode_rows, a.xt_table, a.out, npack);
+  hipLaunchKernelGGL((dcp_cost_pack_kernel<Q, S, LATE, WAVES>), dim3((unsigned)npack), dim3(64), 0, a.stream, a.pool,
+                     a.profiles, packs, a.code_rows, ncode_rows, a.xt_table, a.out, npack);
   return hipGetLastError();
 }
 
@@ -1058,14 +1066,14 @@ hipError_t dcp_launch_cost_pack(int shape, DcpLaunch const &a, DcpPack const *pa
 // wavefronts per workgroup of the LDS variants, by shape: as many as the registers let a CU hold.  Groups of 32
 // lanes keep every row in L2: two rows per load are not what binds them, and the LDS variants measured 3-5 %
 // slower there (K = 93: 711 against 745 GCUPS) while groups of 8 and 16 gained up to 27 % (K = 28: 580 -> 737).
-static int const pack_lds_wg[DCP_NUM_PACK_SHAPES] = {16, 16, 8, 16, 8, 16, 12, 8, 0, 0, 0};
+static int const pack_lds_wg[DCP_NUM_PACK_SHAPES] = {16, 16, 12, 16, 12, 16, 12, 12, 0, 0, 0};
 int dcp_pack_lds_waves(int shape) { return shape >= 0 && shape < DCP_NUM_PACK_SHAPES ? pack_lds_wg[shape] : 0; }
 
-template <int Q, int S, int WG, int NLDS>
+template <int Q, int S, int WG, int NLDS, bool LATE = DCP_PACK_LATE(Q)>
 static hipError_t launch_pack_lds(DcpLaunch const &a, DcpPack const *packs, int2 const *groups, int ngroups, uint32_t ncode_rows)
 {
-  hipLaunchKernelGGL((dcp_cost_pack_lds_kernel<Q, S, WG, NLDS>), dim3((unsigned)ngroups), dim3(64 * WG), 0, a.stream, a.pool,
-                     a.profiles, packs, groups, a.code_rows, ncode_rows, a.xt_table, a.out, ngroups);
+  hipLaunchKernelGGL((dcp_cost_pack_lds_kernel<Q, S, WG, NLDS, LATE>), dim3((unsigned)ngroups), dim3(64 * WG), 0, a.stream,
+                     a.pool, a.profiles, packs, groups, a.code_rows, ncode_rows, a.xt_table, a.out, ngroups);
   return hipGetLastError();
 }
 
@@ -1077,12 +1085,12 @@ hipError_t dcp_launch_cost_pack_lds(int shape, DcpLaunch const &a, DcpPack const
   {
   case 0: return launch_pack_lds<1, 4, 16, 5>(a, packs, groups, ngroups, ncode_rows);  // 44 KB
   case 1: return launch_pack_lds<2, 4, 16, 5>(a, packs, groups, ngroups, ncode_rows);  // 65 KB
-  case 2: return launch_pack_lds<4, 4, 8, 5>(a, packs, groups, ngroups, ncode_rows);   // 87 KB
+  case 2: return launch_pack_lds<4, 4, 12, 5>(a, packs, groups, ngroups, ncode_rows);  // 87 KB
   case 3: return launch_pack_lds<2, 8, 16, 4>(a, packs, groups, ngroups, ncode_rows);  // 27 KB
-  case 4: return launch_pack_lds<4, 8, 8, 4>(a, packs, groups, ngroups, ncode_rows);   // 44 KB
+  case 4: return launch_pack_lds<4, 8, 12, 4>(a, packs, groups, ngroups, ncode_rows);  // 44 KB
   case 5: return launch_pack_lds<2, 16, 16, 4>(a, packs, groups, ngroups, ncode_rows); // 49 KB
   case 6: return launch_pack_lds<3, 16, 12, 4>(a, packs, groups, ngroups, ncode_rows); // 71 KB
-  case 7: return launch_pack_lds<4, 16, 8, 4>(a, packs, groups, ngroups, ncode_rows);  // 87 KB
+  case 7: return launch_pack_lds<4, 16, 12, 4>(a, packs, groups, ngroups, ncode_rows);  // 87 KB
   case 8: return launch_pack_lds<2, 32, 16, 4>(a, packs, groups, ngroups, ncode_rows); // 92 KB
   case 9: return launch_pack_lds<3, 32, 12, 4>(a, packs, groups, ngroups, ncode_rows); // 136 KB
   case 10: return launch_pack_lds<4, 32, 8, 3>(a, packs, groups, ngroups, ncode_rows); // 43 KB: lengths 1..3 only

@@ -51,7 +51,14 @@
 #define DCP_PACK_LDS_ROWS(NLDS) ((NLDS) == 5 ? 1364 : (NLDS) == 4 ? 340 : (NLDS) == 3 ? 84 : (NLDS) == 2 ? 20 : 4)
 
 // TURNS = lazy D->D turns taken before the first vote (dcp_lazy_turns, viterbi_body.h)
-template <int Q, int S, int TURNS = dcp_lazy_turns(Q), int NLDS = 0> struct PackWave
+// LATE: the next row's operands are asked for behind the D chain instead of before it (CostWave's POLICY bit 1).  With
+// four positions per lane that is 180 -> 155 VGPRs, three wavefronts per SIMD instead of two: K = 124 913 -> 987 GCUPS,
+// the LDS variants in workgroups of twelve wavefronts +4..7 % (K = 10..60); three positions per lane stay at three
+// wavefronts (148 -> 141 VGPRs) and gain nothing.
+#ifndef DCP_PACK_LATE
+#define DCP_PACK_LATE(Q) ((Q) == 4)
+#endif
+template <int Q, int S, int TURNS = dcp_lazy_turns(Q), int NLDS = 0, bool LATE = DCP_PACK_LATE(Q)> struct PackWave
 {
   static constexpr bool LDSTAB = NLDS > 0;
   static_assert(S == 4 || S == 8 || S == 16 || S == 32, "groups of 4, 8, 16 or 32 lanes");
@@ -230,10 +237,13 @@ template <int Q, int S, int TURNS = dcp_lazy_turns(Q), int NLDS = 0> struct Pack
 
     // this row's operands are consumed: the next row's (its codes arrived a row ago) go out now,
     // together with the codes of the row after it
-    if (l < Lmax)
+    if constexpr (!LATE)
     {
-      fetch_rows();
-      fetch_codes(l + 2);
+      if (l < Lmax)
+      {
+        fetch_rows();
+        fetch_codes(l + 2);
+      }
     }
 
     lf m = M[0];
@@ -272,6 +282,16 @@ template <int Q, int S, int TURNS = dcp_lazy_turns(Q), int NLDS = 0> struct Pack
       x = Dsh0 + DD[0];
     }
 
+    if constexpr (LATE)
+    {
+      sched_fence();
+      if (l < Lmax)
+      {
+        fetch_rows();
+        fetch_codes(l + 2);
+      }
+      sched_fence();
+    }
     // fold row l into the ring (slot P held row l-5, no longer needed)
     lf BM[Q], MM[Q], IM[Q], DM[Q], II[Q], MI[Q];
     get_fold_trans(fold, BM, MM, IM, DM, II, MI);

@@ -111,9 +111,11 @@ int dcp_hip_cost(struct dcp_hip *, int n, struct dcp_hip_window const *, float *
  * into the window array in increasing order and their lrt; hit_window and hit_lrt must hold n entries. */
 int dcp_hip_cost_hits(struct dcp_hip *, int n, struct dcp_hip_window const *, int *nhits, int32_t *hit_window,
                       float *hit_lrt);
-/* The same in two halves: _begin stages the windows and enqueues the kernels and returns while the GPU works (the
- * host may do anything meanwhile but call this engine); _end waits and delivers what dcp_hip_cost_hits would.  One
- * _begin may be outstanding per engine; any other entry point of the engine before its _end is a DCP_EFUNCUSE. */
+/* The same in two halves: _begin stages the windows and enqueues the kernels and returns while the GPU works;
+ * _end waits for the OLDEST batch begun and delivers what dcp_hip_cost_hits would have.  Two batches may be
+ * outstanding per engine (the second queues behind the first, so the GPU does not drain between them); a third
+ * _begin is a DCP_EFUNCUSE.  While batches are outstanding the engine accepts only _begin, _end, the read-only
+ * queries and dcp_hip_path (which has buffers and streams of its own); everything else is a DCP_EFUNCUSE. */
 int dcp_hip_cost_hits_begin(struct dcp_hip *, int n, struct dcp_hip_window const *);
 int dcp_hip_cost_hits_end(struct dcp_hip *, int *nhits, int32_t *hit_window, float *hit_lrt);
 
@@ -128,12 +130,12 @@ int dcp_hip_cost_hits_end(struct dcp_hip *, int *nhits, int32_t *hit_window, flo
  * A window with no finite path at all (viterbi_cost = +inf, which the reference never sends
  * here: c-core/thread.c:118-121) yields 0 steps and score +inf. */
 int dcp_hip_path(struct dcp_hip *, int n, struct dcp_hip_window const *);
-/* how many windows of the last dcp_hip_path needed the literal pass */
 /* Sets aside `bytes` of HBM for the DP tables of dcp_hip_path now (never shrinks).  VRAM is
  * cleared when allocated, in the background: called early (before the profiles are loaded) the
  * clearing overlaps the load and the cost pass.  Clamped to a quarter of the free device memory.
  * Optional: dcp_hip_path allocates on demand. */
 int dcp_hip_path_reserve(struct dcp_hip *, int64_t bytes);
+/* how many windows of the last dcp_hip_path needed the literal pass */
 int dcp_hip_path_redone(struct dcp_hip const *);
 /* number of steps of window i's path (S ... T) */
 int dcp_hip_path_nsteps(struct dcp_hip const *, int i);

@@ -11,7 +11,7 @@ thread_local long em_votes = 0, em_votes_true = 0;
 template <int Q, int W>
 static void cost_q(float const *pool, DcpProfileDev const &pf, DcpCodeRow const *codes, int L, float const *xt, float *out)
 {
-  static thread_local CostWave<Q, W> w; // 64*W-lane vectors are large: keep them off the stack
+  static thread_local CostWave<Q, W, false, DCP_COST_POLICY(Q, W)> w; // 64*W-lane vectors are large: keep them off the stack
   w.init(pool, pf, codes, xt);
   w.run(L, out);
 }
@@ -32,7 +32,7 @@ extern "C" int emul_cost(float const *pool, DcpProfileDev const *pf, DcpCodeRow 
   case 808: cost_q<8, 8>(pool, *pf, c, L, xt, out); return 0;
   case 501: cost_q<5, 1>(pool, *pf, c, L, xt, out); return 0; // on the 384-column layout of (6,1)
   case 701: cost_q<7, 1>(pool, *pf, c, L, xt, out); return 0; // on the 512-column layout of (8,1)
-  case 502: cost_q<5, 2>(pool, *pf, c, L, xt, out); return 0; // on the 768-column layout of (6,2)
+  case 1001: cost_q<10, 1>(pool, *pf, c, L, xt, out); return 0; // one wave on the 768-column layout of (6,2)
   case 601: cost_q<6, 1>(pool, *pf, c, L, xt, out); return 0;
   case 602: cost_q<6, 2>(pool, *pf, c, L, xt, out); return 0;
   case 604: cost_q<6, 4>(pool, *pf, c, L, xt, out); return 0;

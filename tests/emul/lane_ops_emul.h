@@ -50,6 +50,7 @@ inline lu operator*(lu a, uint32_t b) { lu r; EM_FOR r.v[i_] = a.v[i_] * b; retu
 inline lu operator<<(lu a, int b) { lu r; EM_FOR r.v[i_] = a.v[i_] << b; return r; }
 inline lu operator|(lu a, lu b) { lu r; EM_FOR r.v[i_] = a.v[i_] | b.v[i_]; return r; }
 
+inline void sched_fence() {}
 inline lu lane_ids() { lu r; EM_FOR r.v[i_] = (uint32_t)i_; return r; }
 
 inline lf lane_shift_up(lf x, float fill)
@@ -85,6 +86,7 @@ inline uint32_t read_laneu(lu x, int lane) { return x.v[lane]; }
 enum { GS_M, GS_I, GS_D, GS_E, GS_F, GS_X, GS_T0, GS_T1, GS_X0, GS_X1, GS_SLOTS };
 
 // rows of the cost pass that took the exchange-until-stable fallback (tests read and reset it)
+template <int Q> struct DcpStashChunk { static constexpr int N = Q % 4 == 0 ? 4 : Q % 2 == 0 ? 2 : 1; }; // as lane_ops_gpu.h
 extern thread_local long em_fallback_rows; // defined in emul.cpp: one counter for every translation unit
 
 template <int W> struct Group
@@ -160,9 +162,13 @@ template <int W> struct Group
     J = X.v[1];
   }
   // values parked between uses (LDS on the GPU)
-  lf stashv[8][8];
-  template <int Q> void stash_q(int slot, lf const (&v)[Q]) { for (int q = 0; q < Q; ++q) stashv[slot][q] = v[q]; }
-  template <int Q> void unstash_q(int slot, lf (&v)[Q]) { for (int q = 0; q < Q; ++q) v[q] = stashv[slot][q]; }
+  lf stashv[8][16];
+  template <int Q, int SLOTS> void stash_q(int slot, lf const (&v)[Q]) { for (int q = 0; q < Q; ++q) stashv[slot][q] = v[q]; }
+  template <int Q, int SLOTS> void unstash_q(int slot, lf (&v)[Q]) { for (int q = 0; q < Q; ++q) v[q] = stashv[slot][q]; }
+  template <int Q, int SLOTS> void unstash_chunk(int slot, int j, lf (&v)[DcpStashChunk<Q>::N])
+  {
+    for (int i = 0; i < DcpStashChunk<Q>::N; ++i) v[i] = stashv[slot][DcpStashChunk<Q>::N * j + i];
+  }
   // ---- StripWave ----
   Rec carry[2];
   float tdds[64][16];

@@ -75,11 +75,13 @@ def test_tie_rich_random_cases(em, orc):
 
 
 def test_one_position_per_lane_less_on_the_class_layout(em, orc):
-    """dcp_launch_cost_narrow: K <= 320 / 448 / 640 run as (5,1) / (7,1) / (5,2) on the tables padded for
+    """dcp_launch_cost_narrow: K <= 320 / 448 / 640 run as (5,1) / (7,1) / (10,1) on the tables padded for
     (6,1) / (8,1) / (6,2) -- the same bits as the oracle (and therefore as the class's own shape)."""
     rng = np.random.default_rng(21)
-    cases = [(257, 6, 1, 5), (300, 6, 1, 5), (320, 6, 1, 5), (385, 8, 1, 7), (448, 8, 1, 7), (513, 6, 2, 5), (640, 6, 2, 5)]
-    for it, (K, Q, W, QA) in enumerate(cases * 2):
+    cases = [(257, 6, 1, 5, 1), (300, 6, 1, 5, 1), (320, 6, 1, 5, 1), (385, 8, 1, 7, 1), (448, 8, 1, 7, 1),
+             # one wavefront of 10 positions per lane on the two-wave layout of 768 columns
+             (513, 6, 2, 10, 1), (601, 6, 2, 10, 1), (640, 6, 2, 10, 1)]
+    for it, (K, Q, W, QA, WA) in enumerate(cases * 2):
         quant = [None, 2.0][it % 2]
         prof = synth_profile(rng, K, quant, [0, 0.05][it % 2])
         if it >= len(cases):  # cheap delete runs: the lazy loop carries across lanes (and waves)
@@ -91,6 +93,7 @@ def test_one_position_per_lane_less_on_the_class_layout(em, orc):
             xt = (np.round(xt / quant) * quant).astype(np.float32)
         pool, pd = pack_profile(prof, Q, W)
         pd.Q = QA
+        pd.W = WA
         rows = code_rows(seq)
         xt16 = np.zeros(16, np.float32)
         xt16[:13] = xt
