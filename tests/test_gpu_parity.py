@@ -140,8 +140,9 @@ def test_products_tsv_of_the_reference(engine, orc):
 
 
 def test_one_position_per_lane_less_than_the_class_layout(engine, orc, monkeypatch):
-    """K <= 320 / 448 / 640 run (5,1) / (7,1) / (5,2) on the tables of (6,1) / (8,1) / (6,2)
-    (dcp_launch_cost_narrow): the oracle's bits, and the bits of the class's own shape (DECIPHON_HIP_NARROW=0)."""
+    """K <= 320 / 448 / 640 run (5,1) / (7,1) / (10,1) -- ONE wavefront of ten positions per lane -- on the tables of
+    (6,1) / (8,1) / (6,2) (dcp_launch_cost_narrow): the oracle's bits, and the bits of the class's own shape
+    (DECIPHON_HIP_NARROW=0)."""
     rng = np.random.default_rng(404)
     Ks = (257, 300, 320, 321, 384, 385, 448, 449, 512, 513, 600, 640, 641, 768)
     profs = [synth_profile(rng, K, [None, 2.0][i % 2], [0.0, 0.05][i % 2]) for i, K in enumerate(Ks)]
