@@ -64,8 +64,9 @@ template <int Q, int S, int TURNS = dcp_lazy_turns(Q), int NLDS = 0, bool LATE =
   static_assert(S == 4 || S == 8 || S == 16 || S == 32, "groups of 4, 8, 16 or 32 lanes");
   enum { G = 64 / S, CAP = (S - 1) * Q };
   // Q = 3, 4: the six transition arrays the fold uses once per row wait in LDS (6 KB per wavefront) instead of
-  // 6Q registers -- the difference between two and three (Q = 4), three and four (Q = 3) wavefronts per SIMD,
-  // and throughput goes with the wavefronts in flight.  MD and DD (the D chain and its turns) stay.
+  // 6Q registers: 148 VGPRs with three positions per lane (three wavefronts per SIMD), 180 with four -- 155 and a
+  // third wavefront per SIMD once the next row's operands are requested late (LATE).  MD and DD (the D chain and its
+  // turns) stay in registers.
 #ifndef DCP_PACK_STASH
 #define DCP_PACK_STASH 1
 #endif
