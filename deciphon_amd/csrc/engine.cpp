@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <deque>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -171,7 +172,11 @@ struct PathResult
   size_t trellis_off = 0;      // bytes into d_trellis, valid when has_trellis
   bool has_trellis = false;    // the literal path kernel has run for this window
   bool trellis_on_host = false;
-  std::vector<int32_t> state_ids, seqsizes;
+  // the unzipped path, one word per step: state id (c-core/state.h:9-25) | emission length << 16 -- as the device
+  // wrote it, in the pinned buffer it came back in (dcp_hip::h_steps), or in `owned` when the host unzipped the trellis
+  uint32_t const *steps = nullptr;
+  int32_t nsteps = 0;
+  std::vector<uint32_t> owned;
 };
 
 } // namespace
@@ -256,7 +261,10 @@ struct dcp_hip
   int path_redone = 0;                   // how many of them needed the literal pass
   int path_group = 1;                    // blocks of a window computed side by side in the fast path pass
   PinBuf<int32_t> h_nsteps;        // path pass results on the host (pinned: see PinBuf)
-  PinBuf<uint32_t> h_steps;
+  // the steps of a dcp_hip_path call stay where the copies from the device put them (PathResult::steps points there):
+  // one pinned buffer per slice of the fast pass and one for the literal pass, reused by the next call
+  std::deque<PinBuf<uint32_t>> h_steps;
+  size_t h_steps_used = 0;
   PinBuf<float> h_out;
   DevBuf<uint32_t> d_steps, d_compact;
   DevBuf<int64_t> d_step_off, d_compact_off;
@@ -1574,28 +1582,19 @@ int fetch_steps(dcp_hip *x, int n, int32_t const *&nsteps, std::vector<int64_t> 
   if (!total) return 0;
   HIP_TRY(x, x->d_compact_off.reserve((size_t)n + 1), DCP_ENOMEM);
   HIP_TRY(x, x->d_compact.reserve(total), DCP_ENOMEM);
-  HIP_TRY(x, x->h_steps.reserve(total), DCP_ENOMEM);
+  if (x->h_steps_used == x->h_steps.size()) x->h_steps.emplace_back();
+  PinBuf<uint32_t> &h_steps = x->h_steps[x->h_steps_used++];
+  HIP_TRY(x, h_steps.reserve(total), DCP_ENOMEM);
   HIP_TRY(x, hipMemcpyAsync(x->d_compact_off.p, compact.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
                             x->stream),
           DCP_EFUNCUSE);
   HIP_TRY(x, dcp_launch_compact_steps(x->d_steps.p, x->d_step_off.p, x->d_compact_off.p, x->d_compact.p, n, x->stream),
           DCP_EFUNCUSE);
-  HIP_TRY(x, hipMemcpyAsync(x->h_steps.p, x->d_compact.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream),
+  HIP_TRY(x, hipMemcpyAsync(h_steps.p, x->d_compact.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, x->stream),
           DCP_EFUNCUSE);
   HIP_TRY(x, hipStreamSynchronize(x->stream), DCP_EFUNCUSE);
-  steps = x->h_steps.p;
+  steps = h_steps.p;
   return 0;
-}
-
-void unpack_steps(uint32_t const *s, int32_t ns, PathResult &r)
-{
-  r.state_ids.resize((size_t)ns);
-  r.seqsizes.resize((size_t)ns);
-  for (int32_t i = 0; i < ns; ++i)
-  {
-    r.state_ids[(size_t)i] = (int32_t)(s[i] & 0xffffu);
-    r.seqsizes[(size_t)i] = (int32_t)(s[i] >> 16);
-  }
 }
 
 int fetch_trellis(dcp_hip *x, int i)
@@ -1715,21 +1714,30 @@ int path_literal(dcp_hip *x, std::vector<int> const &idx)
     r.trellis_off = (size_t)p.trellis;
     r.has_trellis = true;
     r.trellis_on_host = false;
-    r.state_ids.clear();
-    r.seqsizes.clear();
+    r.steps = nullptr;
+    r.nsteps = 0;
+    r.owned.clear();
     int32_t const ns = nsteps[(size_t)p.out];
     // a window with no finite path at all (score +inf) has no steps: the reference never walks such
     // a trellis (process_window stops at a non-finite lrt, c-core/thread.c:118-121)
     if (!(r.score < INFINITY)) continue;
     if (ns >= 0)
-      unpack_steps(steps + compact[(size_t)p.out], ns, r);
+    {
+      r.steps = steps + compact[(size_t)p.out];
+      r.nsteps = ns;
+    }
     else
     {
       // the device buffer was too small for this path: fetch the trellis and unzip here
       if ((rc = fetch_trellis(x, i))) return rc;
       uint32_t const *xn = reinterpret_cast<uint32_t const *>(x->host_trellis[(size_t)i].data());
       uint16_t const *nd = reinterpret_cast<uint16_t const *>(xn + (r.L + 1));
-      if ((rc = dcp_unzip(r.K, r.L, xn, nd, r.state_ids, r.seqsizes))) return fail(x, rc, "trellis_unzip failed");
+      std::vector<int32_t> ids, sizes;
+      if ((rc = dcp_unzip(r.K, r.L, xn, nd, ids, sizes))) return fail(x, rc, "trellis_unzip failed");
+      r.owned.resize(ids.size());
+      for (size_t k = 0; k < ids.size(); ++k) r.owned[k] = (uint32_t)ids[k] | ((uint32_t)sizes[k] << 16);
+      r.steps = r.owned.data();
+      r.nsteps = (int32_t)r.owned.size();
     }
   }
   return 0;
@@ -1868,13 +1876,13 @@ int path_fast(dcp_hip *x, int b, int e, std::vector<int> &redo)
     r.L = p.L;
     r.score = out[2 * (size_t)p.out + 1]; // the alt score of the same DP
     r.has_trellis = r.trellis_on_host = false;
+    r.owned.clear();
     int32_t const ns = nsteps[(size_t)p.out];
-    if (ns >= 0)
-      unpack_steps(steps + compact[(size_t)p.out], ns, r);
-    else
-      redo.push_back(x->path_order[(size_t)(b + p.out)]);
+    r.steps = ns >= 0 ? steps + compact[(size_t)p.out] : nullptr;
+    r.nsteps = ns >= 0 ? ns : 0;
+    if (ns < 0) redo.push_back(x->path_order[(size_t)(b + p.out)]);
   }
-  tm.lap("unpack");
+  tm.lap("results");
   if (tm.on)
     fprintf(stderr, "dcp_hip_path: %d windows, tables %.2f GB of %.2f GB held (hipMalloc %.1f ms), %zu steps, %zu to redo;%s\n",
             n, (double)x->tables.placed / 1e9, (double)x->tables.held / 1e9, x->tables.alloc_ms, total_fetched,
@@ -1909,6 +1917,7 @@ int dcp_hip_path(struct dcp_hip *x, int n, struct dcp_hip_window const *w)
   if (!x || n < 0 || (n > 0 && !w)) return DCP_EFUNCUSE;
   HIP_TRY(x, hipSetDevice(x->device), DCP_EFUNCUSE);
   PathContext ctx(x); // its own window lists, result buffers and streams: cost batches may be in flight
+  x->h_steps_used = 0;
   x->paths.clear();
   x->path_wins.assign(w, w + n);
   x->paths.resize((size_t)n);
@@ -2026,15 +2035,26 @@ int dcp_hip_path_reserve(struct dcp_hip *x, int64_t bytes)
 int dcp_hip_path_nsteps(struct dcp_hip const *x, int i)
 {
   if (!x || i < 0 || i >= (int)x->paths.size()) return -1;
-  return (int)x->paths[(size_t)i].state_ids.size();
+  return (int)x->paths[(size_t)i].nsteps;
 }
 
 int dcp_hip_path_steps(struct dcp_hip const *x, int i, int32_t *state_ids, int32_t *seqsizes)
 {
   if (!x || i < 0 || i >= (int)x->paths.size() || !state_ids || !seqsizes) return DCP_EFUNCUSE;
   PathResult const &r = x->paths[(size_t)i];
-  memcpy(state_ids, r.state_ids.data(), r.state_ids.size() * sizeof(int32_t));
-  memcpy(seqsizes, r.seqsizes.data(), r.seqsizes.size() * sizeof(int32_t));
+  for (int32_t k = 0; k < r.nsteps; ++k)
+  {
+    state_ids[k] = (int32_t)(r.steps[k] & 0xffffu);
+    seqsizes[k] = (int32_t)(r.steps[k] >> 16);
+  }
+  return 0;
+}
+
+int dcp_hip_path_steps_packed(struct dcp_hip const *x, int i, uint32_t const **steps, int32_t *nsteps)
+{
+  if (!x || i < 0 || i >= (int)x->paths.size() || !steps || !nsteps) return DCP_EFUNCUSE;
+  *steps = x->paths[(size_t)i].steps;
+  *nsteps = x->paths[(size_t)i].nsteps;
   return 0;
 }
 

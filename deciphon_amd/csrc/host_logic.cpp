@@ -255,11 +255,13 @@ bool dcp_state_is_mute(int id)
   return msb(id) == ST_D;
 }
 
-bool dcp_find_hit(std::vector<int32_t> const &ids, std::vector<int32_t> const &sizes, DcpHit &hit)
+namespace
 {
-  int const n = (int)ids.size();
+// c-core/thread.c:130-160 (the span between the first B and the last E of the path), over any view of the steps
+template <class Id, class Size> bool find_hit(int n, Id id, Size size, DcpHit &hit)
+{
   int it = 0, pos = 0;
-  while (it < n && ids[it] != ST_B) pos += sizes[it++];
+  while (it < n && id(it) != ST_B) pos += size(it++);
   if (it >= n) return false;
   hit.hit_start = pos;
   hit.begin_step = it;
@@ -269,13 +271,24 @@ bool dcp_find_hit(std::vector<int32_t> const &ids, std::vector<int32_t> const &s
   {
     it = end;
     hit.hit_stop = stop;
-    while (it < n && ids[it] != ST_E) stop += sizes[it++];
+    while (it < n && id(it) != ST_E) stop += size(it++);
     if (it >= n) break;
     end = it + 1;
   }
   hit.end_step = end;
   hit.last_hit_pos = hit.hit_stop - 1;
   return true;
+}
+} // namespace
+
+bool dcp_find_hit(std::vector<int32_t> const &ids, std::vector<int32_t> const &sizes, DcpHit &hit)
+{
+  return find_hit((int)ids.size(), [&](int i) { return ids[(size_t)i]; }, [&](int i) { return sizes[(size_t)i]; }, hit);
+}
+
+bool dcp_find_hit_packed(uint32_t const *steps, int n, DcpHit &hit)
+{
+  return find_hit(n, [&](int i) { return (int)(steps[i] & 0xffffu); }, [&](int i) { return (int)(steps[i] >> 16); }, hit);
 }
 
 bool DcpWindow::next()

@@ -38,6 +38,8 @@ struct DcpHit
   int last_hit_pos;         // what window_set_last_hit_position receives
 };
 bool dcp_find_hit(std::vector<int32_t> const &state_ids, std::vector<int32_t> const &seqsizes, DcpHit &hit);
+// the same on packed steps (state id | emission length << 16, dcp_hip_path_steps_packed)
+bool dcp_find_hit_packed(uint32_t const *steps, int n, DcpHit &hit);
 
 // c-core/window.c:7-37
 struct DcpWindow

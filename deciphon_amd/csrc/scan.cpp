@@ -29,6 +29,7 @@
 #include <string.h>
 #include <deque>
 #include <map>
+#include <future>
 #include <mutex>
 #include <memory>
 #include <string>
@@ -137,9 +138,12 @@ struct Row
 // (c-core/match.c:66-89, c-core/decoder.c:38-58) for the emitting states.  *rc receives DCP_EDECODON when a step
 // cannot be decoded (the reference fails the scan there).
 std::string format_row(dcp_batch::Seq const &seq, int window, int wstart, int wstop, DcpHit const &hit,
-                       char const *accession, char const *abc, float lrt, std::vector<int32_t> const &ids,
-                       std::vector<int32_t> const &sizes, DcpDecoder const &dec, std::atomic<int> *rc)
+                       char const *accession, char const *abc, float lrt, uint32_t const *steps,
+                       DcpDecoder const &dec, std::atomic<int> *rc)
 {
+  // a step: state id in the low 16 bits, emission length above (dcp_hip_path_steps_packed)
+  auto step_id = [&](int i) { return (int)(steps[i] & 0xffffu); };
+  auto step_size = [&](int i) { return (int)(steps[i] >> 16); };
   char const *sym = seq.has_u ? "ACGU" : "ACGT";
   char head[256];
   snprintf(head, sizeof head, "%ld\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%s\t%.1f\tnan\t", seq.id, window, wstart, wstop, 0,
@@ -147,13 +151,13 @@ std::string format_row(dcp_batch::Seq const &seq, int window, int wstart, int ws
   std::string out = head;
   out.reserve(out.size() + (size_t)(hit.end_step - hit.begin_step) * 12);
   int pos = 0;
-  for (int i = 0; i < hit.begin_step; ++i) pos += sizes[(size_t)i];
+  for (int i = 0; i < hit.begin_step; ++i) pos += step_size(i);
   for (int i = hit.begin_step; i < hit.end_step; ++i)
   {
     if (i > hit.begin_step) out += ';';
     char name[8];
-    dcp_state_name(ids[(size_t)i], name);
-    int const n = sizes[(size_t)i], id = ids[(size_t)i];
+    int const n = step_size(i), id = step_id(i);
+    dcp_state_name(id, name);
     out.append(seq.text, (size_t)(wstart + pos), (size_t)n);
     out += ',';
     out += name;
@@ -359,10 +363,15 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
     int profile, seq, widx, wstart, wstop;
     float lrt;
     DcpHit hit;
-    std::vector<int32_t> ids, sizes;
+    // the path: first where the engine holds it (dcp_hip_path_steps_packed), then a copy of the job's own -- the
+    // formatter threads make it first thing, and the next path pass waits for them to have made it (steps_copied)
+    uint32_t const *steps = nullptr;
+    int32_t nsteps = 0;
+    std::vector<uint32_t> owned;
     std::shared_ptr<dcp_scan::LazyDecoder> dec;
   };
   std::deque<std::vector<Row>> formatted;
+  std::shared_future<void> steps_copied; // set once the formatters of the last path batch hold their own copies of the steps
   std::atomic<int> decode_rc{0};
   x->decoders.resize((size_t)std::max(dcp_hip_num_profiles(x->eng), 0));
   struct Joiner
@@ -518,20 +527,46 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
       }
     }
     ph.windows += ph.lap();
+    if (steps_copied.valid()) steps_copied.wait(); // the previous batch's formatters still read the engine's step buffers
+    steps_copied = std::shared_future<void>();
     int prc = dcp_hip_path(x->eng, (int)hits.size(), hits.data());
     if (prc) return raise(prc, __func__, dcp_hip_strerror(x->eng));
     ph.path += ph.lap();
-    // hit spans first (they move the window chains); the rows are then formatted by up to 16 host threads (a row
-    // is a few thousand short appends) while the GPU goes on
+    // hit spans first (they move the window chains: a few threads, 6 M steps to walk for the headline's 2301 hits); the
+    // rows are then formatted by up to 16 host threads (a row is a few thousand short appends) while the GPU goes on
+    std::vector<Job> found(batch_p.size());
+    std::vector<char> is_hit(batch_p.size(), 0);
+    {
+      std::atomic<size_t> next_hit{0};
+      std::atomic<int> steps_rc{0};
+      dcp_hip const *eng = x->eng;
+      auto spans = [&]() {
+        for (size_t h = next_hit.fetch_add(16); h < found.size(); h = next_hit.fetch_add(16))
+          for (size_t i = h, e = std::min(found.size(), h + 16); i < e; ++i)
+          {
+            Job &j = found[i];
+            if (int const src = dcp_hip_path_steps_packed(eng, (int)i, &j.steps, &j.nsteps))
+            {
+              int expected = 0;
+              steps_rc.compare_exchange_strong(expected, src);
+              continue;
+            }
+            is_hit[i] = dcp_find_hit_packed(j.steps, j.nsteps, j.hit) ? 1 : 0;
+          }
+      };
+      unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 8u,
+                                                    (unsigned)std::max<size_t>(found.size() / 64, 1)});
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(spans);
+      spans();
+      for (std::thread &t : pool) t.join();
+      if (steps_rc) return raise(steps_rc, __func__);
+    }
     auto jobs = std::make_shared<std::vector<Job>>();
     for (size_t h = 0; h < batch_p.size(); ++h)
     {
-      int const n = dcp_hip_path_nsteps(x->eng, (int)h);
-      Job j;
-      j.ids.resize((size_t)n);
-      j.sizes.resize((size_t)n);
-      if ((prc = dcp_hip_path_steps(x->eng, (int)h, j.ids.data(), j.sizes.data()))) return raise(prc, __func__);
-      if (!dcp_find_hit(j.ids, j.sizes, j.hit)) continue;
+      if (!is_hit[h]) continue;
+      Job &j = found[h];
       PairState &ps = st[batch_p[h].pair];
       ps.win.last_hit_pos = j.hit.last_hit_pos; // window_set_last_hit_position, c-core/thread.c:162
       j.profile = ps.profile;
@@ -550,9 +585,21 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
       std::vector<Row> *out = &formatted.back();
       dcp_scan const *scan = x;
       std::atomic<int> *drc = &decode_rc;
-      formatters.add(std::thread([jobs, out, scan, batch, drc]() {
-        std::atomic<size_t> next_job{0};
+      auto copied = std::make_shared<std::promise<void>>();
+      steps_copied = copied->get_future().share();
+      std::shared_future<void> all_copied = steps_copied;
+      formatters.add(std::thread([jobs, out, scan, batch, drc, copied, all_copied]() {
+        std::atomic<size_t> next_copy{0}, ncopied{0}, next_job{0};
         auto work = [&]() {
+          // the steps out of the engine's buffers first: the scan's next path pass waits for that, not for the rows
+          for (size_t k = next_copy.fetch_add(1); k < jobs->size(); k = next_copy.fetch_add(1))
+          {
+            Job &j = (*jobs)[k];
+            j.owned.assign(j.steps, j.steps + j.nsteps);
+            j.steps = j.owned.data();
+            if (ncopied.fetch_add(1) + 1 == jobs->size()) copied->set_value();
+          }
+          all_copied.wait(); // (a job may be formatted by another thread than the one that copied it)
           for (size_t k = next_job.fetch_add(1); k < jobs->size(); k = next_job.fetch_add(1))
           {
             Job const &j = (*jobs)[k];
@@ -568,7 +615,7 @@ int dcp_scan_run(struct dcp_scan *x, struct dcp_batch *batch, char const *produc
             (*out)[k] = Row{j.profile, j.seq, j.widx,
                             format_row(seq, j.widx, j.wstart, j.wstop, j.hit,
                                        dcp_hip_profile_accession(scan->eng, j.profile), scan->abc_name.c_str(),
-                                       j.lrt, j.ids, j.sizes, ld.dec, drc)};
+                                       j.lrt, j.steps, ld.dec, drc)};
           }
         };
         unsigned const nthreads = std::min<unsigned>({std::max(1u, std::thread::hardware_concurrency()), 16u,

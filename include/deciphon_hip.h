@@ -141,6 +141,10 @@ int dcp_hip_path_redone(struct dcp_hip const *);
 int dcp_hip_path_nsteps(struct dcp_hip const *, int i);
 /* state ids (c-core/state.h:9-25, state.c:92-96) and emission lengths of every step */
 int dcp_hip_path_steps(struct dcp_hip const *, int i, int32_t *state_ids, int32_t *seqsizes);
+/* The same without a copy: *steps points at window i's *nsteps steps as the engine holds them, one word each --
+ * state id in the low 16 bits, emission length in the high -- valid until the next dcp_hip_path / dcp_hip_del
+ * (what struct imm_step carries apart from the score, c-core/trellis.c:147-167). */
+int dcp_hip_path_steps_packed(struct dcp_hip const *, int i, uint32_t const **steps, int32_t *nsteps);
 /* the packed back-pointers themselves: xnodes[L+1], nodes[(L+1)*K] (c-core/trellis.h:12-21) */
 int dcp_hip_path_trellis(struct dcp_hip const *, int i, uint32_t const **xnodes, uint16_t const **nodes);
 /* score of the path pass's own DP (equals alt_cost of dcp_hip_cost) */
