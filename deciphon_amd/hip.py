@@ -82,6 +82,7 @@ def load_library() -> C.CDLL:
     L.dcp_hip_path_reserve.argtypes = [vp, C.c_int64]
     L.dcp_hip_path_nsteps.argtypes = [vp, i32]
     L.dcp_hip_path_steps.argtypes = [vp, i32, vp, vp]
+    L.dcp_hip_path_steps_packed.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_int32)]
     L.dcp_hip_path_trellis.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.dcp_hip_path_score.argtypes = [vp, i32]
     L.dcp_hip_path_score.restype = C.c_float
@@ -304,6 +305,14 @@ class Engine:
     def path_reserve(self, nbytes: int):
         """Set HBM aside for the path pass's DP tables now (its clearing overlaps what follows)."""
         self._check(self.lib.dcp_hip_path_reserve(self.h, int(nbytes)))
+
+    def path_steps_packed(self, i: int) -> np.ndarray:
+        """Window i's steps of the last path() as the engine holds them (state id | emission length << 16), copied."""
+        p, n = C.c_void_p(), C.c_int32(0)
+        self._check(self.lib.dcp_hip_path_steps_packed(self.h, i, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.uint32)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
 
     def path(self, windows, trellis: bool = True):
         """viterbi_path + trellis_unzip -> list of dicts(score, state_ids, seqsizes[, xnodes, nodes]).

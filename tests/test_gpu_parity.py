@@ -486,8 +486,19 @@ def test_fast_path_pass_equals_literal_pass(engine, orc):
         assert bits(r["score"]) == bits(score) == bits(r["literal_score"])
         assert np.array_equal(r["xnodes"], xo) and np.array_equal(r["nodes"], no)
     untied = [i for i, q in enumerate(quants) if q is None]
-    engine.path([wins[i] for i in untied], trellis=False)
+    fast = engine.path([wins[i] for i in untied], trellis=False)
     assert engine.path_redone == 0  # continuous costs: the fast pass alone
+    # dcp_hip_path_steps_packed: the same steps without the copy, a word each (state id | emission length << 16) --
+    # of the fast pass here, of a mix of both passes (literal redo's among them) after the next call
+    for j, r in enumerate(fast):
+        pk = engine.path_steps_packed(j)
+        assert np.array_equal(pk & 0xFFFF, r["state_ids"].astype(np.uint32)) and np.array_equal(pk >> 16, r["seqsizes"].astype(np.uint32))
+    mixed = engine.path(wins, trellis=False)
+    assert engine.path_redone > 0
+    for j, r in enumerate(mixed):
+        pk = engine.path_steps_packed(j)
+        assert np.array_equal(pk & 0xFFFF, r["state_ids"].astype(np.uint32)) and np.array_equal(pk >> 16, r["seqsizes"].astype(np.uint32))
+        assert np.array_equal(r["state_ids"], res[j]["state_ids"]) and np.array_equal(r["seqsizes"], res[j]["seqsizes"])
 
 
 def test_path_pass_slices_by_table_memory(engine, orc, monkeypatch):
