@@ -27,14 +27,21 @@ template <class T> __device__ __forceinline__ T *dcp_global(uintptr_t address)
 // problem list) land on all eight L2s and every L2 holds the tables of every profile in flight.  This gives
 // XCD x the x-th contiguous eighth of the list instead (the bijective form for any grid size), so an L2 sees
 // an eighth of the profiles.  A speed choice only: nothing depends on where a workgroup runs.
+__device__ __forceinline__ int dcp_xcd_remap_any(int b, int n)
+{
+  int const q = n >> 3, r = n & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
 __device__ __forceinline__ int dcp_xcd_remap(int b, int n)
 {
   // a launch of about one generation of wavefronts keeps the plain order: there the eighths would be uneven in
   // time (windows of different profiles take different time) with nothing left to even them out
-  if (n < 16384) return b;
-  int const q = n >> 3, r = n & 7, x = b & 7;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  return n < 16384 ? b : dcp_xcd_remap_any(b, n);
 }
+// The path pass's kernels take the eighths whatever the size of the launch: all their wavefronts are resident at once
+// (nothing to even out), and what they wait for is memory -- the 2301 hit windows of the headline scan fetch 140 GB of
+// emission rows and write 66 GB of tables in 50 ms (scripts/pmc_path.sh).  With the windows of a profile on one XCD
+// instead of all eight, the pass takes 46.5 ms instead of 51 (profiles/r03_path_pass_pmc.txt).
 
 // Wavefronts per SIMD the register allocator must leave room for.  A wavefront issues a VALU every ~7.5 cycles
 // whatever its instruction-level parallelism (profiles/r02_valu_rates.txt), so two wavefronts per SIMD cap the
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_ckpt_kernel
                                                            float *__restrict__ out, int nprob)
 {
   if ((int)blockIdx.x >= nprob) return;
-  DcpProblem const pb = problems[dcp_xcd_remap((int)blockIdx.x, nprob)];
+  DcpProblem const pb = problems[dcp_xcd_remap_any((int)blockIdx.x, nprob)];
   if (dcp_num_blocks(pb.L, B) <= 1) return;
   DcpProfileDev const pf = profiles[pb.profile];
   CostWave<Q, W> w;
@@ -114,13 +121,14 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_cost_store_kerne
   if (G > 0)
   {
     if ((int)blockIdx.x >= nprob * G) return;
-    p = (int)blockIdx.x / G;
-    sub = (int)blockIdx.x % G;
+    int const b = dcp_xcd_remap_any((int)blockIdx.x, nprob * G); // (window, block) pairs in eighths: whole windows, mostly
+    p = b / G;
+    sub = b % G;
   }
   else
   {
     if ((int)blockIdx.x >= nprob) return;
-    p = dcp_xcd_remap((int)blockIdx.x, nprob);
+    p = dcp_xcd_remap_any((int)blockIdx.x, nprob);
   }
   DcpProblem const pb = problems[p];
   if (G > 0) block = dcp_num_blocks(pb.L, B) - 1 - (it * G + sub);
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(64 * W, (Q >= 8 ? 2 : 1)) void dcp_path_blocks_kern
 {
   if ((int)blockIdx.x >= nprob) return;
   __shared__ int walk_over;
-  DcpProblem const pb = problems[blockIdx.x];
+  DcpProblem const pb = problems[dcp_xcd_remap_any((int)blockIdx.x, nprob)];
   DcpProfileDev const pf = profiles[pb.profile];
   DcpCodeRow const *codes = code_rows + pb.code_row;
   float const *xt = xt_table + (size_t)pb.xt_row * DCP_XT_STRIDE;
