@@ -596,23 +596,31 @@ template <> DCP_FN void load_row_q<10>(RowSrc const &r, lu voff, uint32_t soff, 
   out[6] = __uint_as_float(b.z); out[7] = __uint_as_float(b.w); out[8] = __uint_as_float(c.x);
   out[9] = __uint_as_float(c.y);
 }
-// one DP-table row plane: the lane's Q values at row[lane*Q ..], rows padded to Kp
+// one DP-table row plane: the lane's Q values at row[lane*Q ..], rows padded to Kp.
+// Non-temporal stores: tables and checkpoints are written once and read once, by another kernel, 66 GB of them for the
+// headline scan's 2301 hits -- through the L2 they evicted the emission rows every wavefront of the path pass keeps
+// re-reading (the pass: 43.3 -> 35.7 ms on one box, profiles/r03_path_pass_pmc.txt).
 template <int Q> DCP_FN void store_q(float *__restrict__ row, lu lane, lf const (&v)[Q])
 {
+  typedef float dcp_f32x2 __attribute__((ext_vector_type(2)));
+  typedef float dcp_f32x4 __attribute__((ext_vector_type(4)));
   float *p = row + (size_t)lane * Q;
-  if (Q == 1) p[0] = v[0];
-  if (Q == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[Q > 1 ? 1 : 0]);
-  if (Q == 3)
+  if constexpr (Q == 1)
+    __builtin_nontemporal_store(v[0], p);
+  else if constexpr (Q == 2)
   {
-    p[0] = v[0];
-    p[1] = v[Q > 1 ? 1 : 0];
-    p[2] = v[Q > 2 ? 2 : 0];
+    dcp_f32x2 const t = {v[0], v[1]};
+    __builtin_nontemporal_store(t, reinterpret_cast<dcp_f32x2 *>(p));
   }
-  if (Q == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[Q > 1 ? 1 : 0], v[Q > 2 ? 2 : 0], v[Q > 3 ? 3 : 0]);
-  if (Q > 4)
+  else if constexpr (Q == 4)
+  {
+    dcp_f32x4 const t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<dcp_f32x4 *>(p));
+  }
+  else
   {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) p[q] = v[q];
+    for (int q = 0; q < Q; ++q) __builtin_nontemporal_store(v[q], p + q); // (the compiler merges them: x4 + x2 for six)
   }
 }
 
